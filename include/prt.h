@@ -1,0 +1,258 @@
+/*
+ * prt.h — C-ABI of the MI355X-native wavefront path tracer (libprt.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Rickyeeeeee/ParallelRayTracing:
+ *   camera-ray generation -> closest-hit (BVH traversal + shape intersection)
+ *   -> material shade/scatter -> film accumulation.
+ * It replaces what the reference's `class Renderer` backends do
+ * (reference: src/core/renderer.h:8-16 — Init / ProgressiveRender / SetCamera) and the
+ * Film accumulate/display entry points they call (src/core/film.h:10-47).
+ *
+ * Conventions
+ *  - Plain C, no torch / C++ types.  Every call returns 0 on success, nonzero on error;
+ *    prt_last_error() gives the message.  No exception crosses this boundary.
+ *  - Matrices are column-major float[16], exactly glm::mat4's memory layout
+ *    (reference: Transform::m_Mat / m_InvMat, src/core/geometry.h:129-130).
+ *  - The film is row-major, row 0 = top of the image, interleaved RGB fp32 *sums* plus a
+ *    per-pixel weight (reference: Film::m_Accum / m_Weights, src/core/film.h:54-60).
+ *  - All data passed in is COPIED; the library keeps no pointer into caller memory
+ *    (the reference backends keep raw non-owning pointers, src/backend/cpu/renderer.cpp:8-15).
+ *  - Not thread-safe per context; one context drives one GPU.
+ *  - There is NO CPU fallback.  Compute entry points fail with PRT_ERR_NO_DEVICE when no
+ *    HIP device is usable.
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_VERSION 1
+
+/* status codes */
+enum {
+    PRT_OK = 0,
+    PRT_ERR_INVALID = 1,   /* bad argument / call order */
+    PRT_ERR_NO_DEVICE = 2, /* no usable HIP device */
+    PRT_ERR_HIP = 3,       /* a HIP runtime call failed */
+    PRT_ERR_IO = 4,        /* file could not be read / parsed / written */
+    PRT_ERR_NOMEM = 5
+};
+
+/* reference: enum class ShapeType, src/core/shape.h:10-15 */
+enum { PRT_SHAPE_CIRCLE = 0, PRT_SHAPE_QUAD = 1, PRT_SHAPE_TRIANGLE = 2 };
+/* reference: enum MatType, src/core/material_handle.h:13-19 */
+enum { PRT_MAT_NONE = 0, PRT_MAT_LAMBERTIAN = 1, PRT_MAT_METAL = 2, PRT_MAT_DIELECTRIC = 3, PRT_MAT_EMISSIVE = 4 };
+/* reference: enum class ScenePreset, src/core/scene.h:6-15 */
+enum {
+    PRT_PRESET_DEFAULT = 0, PRT_PRESET_LIGHT_TEST = 1, PRT_PRESET_MATERIAL_TEST = 2, PRT_PRESET_CORNELL = 3,
+    PRT_PRESET_RANDOM_BALLS_SMALL = 4, PRT_PRESET_RANDOM_BALLS_MEDIUM = 5, PRT_PRESET_RANDOM_BALLS_LARGE = 6
+};
+
+/* One material.  rgb = albedo (Lambertian, Metal) or emission (Emissive); scalar = roughness
+ * (Metal) or refraction index (Dielectric).
+ * reference: LambertianMaterial/MetalMaterial/DielectricMaterial/EmissiveMaterial getters,
+ * src/core/material.h:38,64-65,102,129. */
+typedef struct PrtMaterial {
+    uint32_t type;
+    float rgb[3];
+    float scalar;
+} PrtMaterial;
+
+/* One analytic primitive = Shape + Material + Transform.
+ * shape_param: CIRCLE {radius, -}; QUAD {width, height}.
+ * reference: struct Primitive, src/core/primitive.h:7-12; Circle::getRadius / Quad::GetWidth/GetHeight,
+ * src/core/shape.h:25,39-40. */
+typedef struct PrtPrimitive {
+    uint32_t shape_type;
+    float shape_param[2];
+    uint32_t material_id;
+    float mat[16];
+    float inv[16];
+} PrtPrimitive;
+
+/* One triangle mesh in WORLD space (its Transform is the identity).  Semantically it is a run of
+ * Triangle primitives (src/core/shape.h:50-81) appended to the primitive list after all analytic
+ * primitives, in face order; vertex data as Mesh exposes it (src/core/mesh.h:12-14):
+ * positions/normals are n_vertices*3 floats, indices n_triangles*3 uint32. normals must not be NULL. */
+typedef struct PrtMesh {
+    const float* positions;
+    const float* normals;
+    const uint32_t* indices;
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    uint32_t material_id;
+} PrtMesh;
+
+typedef struct PrtSceneDesc {
+    const PrtMaterial* materials;
+    const PrtPrimitive* primitives;
+    const PrtMesh* meshes;
+    uint32_t n_materials;
+    uint32_t n_primitives;
+    uint32_t n_meshes;
+    float sky[3]; /* reference literal (0.4,0.3,0.6): src/backend/cpu/renderer.h:31 */
+} PrtSceneDesc;
+
+/* Pinhole camera; right/up are derived exactly as Camera::Camera does (src/core/camera.h:10-16);
+ * vertical FoV is fixed at 1 rad (src/core/camera.h:111). */
+typedef struct PrtCameraDesc {
+    float position[3];
+    float front[3];
+    float width;
+    float height;
+} PrtCameraDesc;
+
+/* Closest-hit record of one ray (what Scene::Intersect returns, src/core/surface_interaction.h:6-13,
+ * plus the winning primitive index and the world distance^2 the reference minimises,
+ * src/core/primitive.cpp:42-48).  prim < 0: miss. */
+typedef struct PrtHit {
+    int32_t prim;
+    uint32_t front_face;
+    uint32_t material_id;
+    float d2;
+    float position[3];
+    float normal[3];
+} PrtHit;
+
+/* Counters and timings of the render calls since the last prt_reset_stats. */
+#define PRT_MAX_DEPTH 64
+typedef struct PrtStats {
+    uint64_t rays_total;               /* ray segments for which a closest-hit query ran */
+    uint64_t rays_per_depth[PRT_MAX_DEPTH];
+    uint64_t samples;                  /* ProgressiveRender-equivalents done */
+    uint64_t intersect_launches;       /* launches of the dominant (closest-hit) kernel */
+    double intersect_ms;               /* summed HIP-event time of those launches (timing enabled) */
+    double shade_ms;
+    double raygen_ms;
+    double accumulate_ms;
+    uint64_t bvh_node_visits;          /* only from prt_measure_traversal */
+    uint64_t bvh_tri_tests;
+    uint64_t prim_tests;
+} PrtStats;
+
+typedef struct PrtBvhInfo {
+    uint32_t n_nodes;
+    uint32_t n_triangles;
+    uint32_t max_depth;
+    uint32_t max_leaf_size;
+    float sah_cost;
+    float pad_abs;     /* absolute AABB padding applied (conservative culling) */
+    uint64_t node_bytes;
+    uint64_t tri_bytes;
+} PrtBvhInfo;
+
+typedef struct PrtContext PrtContext;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+/* device_id < 0: host-only context (scene/mesh/BVH utilities work, compute calls fail loudly). */
+int prt_create(int device_id, PrtContext** out);
+void prt_destroy(PrtContext* ctx);
+const char* prt_last_error(const PrtContext* ctx);
+int prt_version(void);
+/* Launch on this hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+int prt_set_stream(PrtContext* ctx, void* hip_stream);
+
+/* ---- Renderer::Init / SetCamera (src/core/renderer.h:13-15) ---------------------------------- */
+/* Flattens + uploads the scene and builds the BVH over all mesh triangles.  Replaces
+ * BuildWavefrontSceneBuffers (src/backend/cuda_wavefront/soa.cpp:37-114). */
+int prt_set_scene(PrtContext* ctx, const PrtSceneDesc* scene);
+int prt_set_camera(PrtContext* ctx, const PrtCameraDesc* cam);
+/* Film::Resize + Clear (src/core/film.cu:11-35) and the image partition of this context:
+ * 8x8-pixel tiles, tile t (row-major) belongs to rank t % world_size. */
+int prt_set_film(PrtContext* ctx, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size);
+int prt_film_clear(PrtContext* ctx);
+
+/* ---- Renderer::ProgressiveRender (src/core/renderer.h:14) ------------------------------------- */
+/* Adds `spp` samples per pixel (sample indices first_sample .. first_sample+spp-1) to the film.
+ * spp = 1 is exactly one ProgressiveRender.  max_depth = max ray segments per path
+ * (reference m_Depth = 20, src/backend/cpu/renderer.h:34).  Result is independent of batching and
+ * of world_size because the RNG is keyed by (global pixel, sample, seed). Synchronous on return. */
+int prt_render(PrtContext* ctx, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample);
+/* Same, but only enqueues on the stream (no host sync). */
+int prt_render_async(PrtContext* ctx, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample);
+int prt_synchronize(PrtContext* ctx);
+/* Samples kept in flight together (paths = local pixels * n); default 1. */
+int prt_set_samples_in_flight(PrtContext* ctx, uint32_t n);
+
+/* ---- Film read-back (Film::m_Accum / m_Weights; src/core/film.h:54-60) ------------------------ */
+/* Whole film to host, row-major, top-left origin; only pixels owned by this rank are non-zero. */
+int prt_film_read(PrtContext* ctx, float* rgb_sum, float* weight);
+/* Device pointer + float count of this rank's tile-ordered accumulation ([local_tile][64][4] =
+ * r,g,b,weight) — the payload of the per-frame RCCL gather. Padded so every rank has the same count. */
+int prt_film_local(PrtContext* ctx, void** d_ptr, uint64_t* n_floats);
+/* Un-tile a gathered buffer (world_size consecutive rank payloads) into film layout on the device:
+ * d_rgb_sum [H*W*3], d_weight [H*W].  Equivalent of Film::AddSampleBufferGPU's target layout
+ * (src/core/film.cu:79-99). */
+int prt_film_resolve(PrtContext* ctx, const void* d_gathered, uint32_t world_size, void* d_rgb_sum, void* d_weight);
+/* Film::UpdateDisplayGPU (src/core/film.cu:101-132): mean -> Reinhard -> gamma -> RGBA8, from device
+ * film buffers to a device RGBA8 buffer [H*W*4]. */
+int prt_film_tonemap(PrtContext* ctx, const void* d_rgb_sum, const void* d_weight, float exposure, float gamma, void* d_rgba8);
+/* Convenience: resolve this context's own film (world_size==1) and tonemap to host RGBA8. */
+int prt_film_display(PrtContext* ctx, float exposure, float gamma, uint8_t* rgba8);
+
+/* ---- function-level entry points (used by the parity tests; all go through the same kernels) -- */
+/* Camera::GetCameraRay at pixel-space points (px,py)  (src/core/camera.h:103-132). Host in/out. */
+int prt_camera_rays(PrtContext* ctx, uint32_t n, const float* px, const float* py, float* origins, float* dirs);
+/* Scene::Intersect for n rays (src/core/scene.h:22-25).  Host in/out. */
+int prt_closest_hit(PrtContext* ctx, uint32_t n, const float* origins, const float* dirs, PrtHit* hits);
+/* MaterialHandle::Scatter + Emit for n (ray, hit, rng state) tuples (src/core/material.h:139-161).
+ * rng_state is advanced in place. scattered[i] = 0/1. */
+int prt_scatter(PrtContext* ctx, uint32_t n, const float* in_dirs, const PrtHit* hits, uint32_t* rng_state,
+                uint32_t* scattered, float* attenuation, float* emitted, float* out_origins, float* out_dirs);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+int prt_enable_timing(PrtContext* ctx, int on); /* HIP events around every kernel launch */
+int prt_get_stats(PrtContext* ctx, PrtStats* out);
+int prt_reset_stats(PrtContext* ctx);
+/* Runs ONE sample with the instrumented traversal kernel (film untouched) and fills
+ * bvh_node_visits / bvh_tri_tests / prim_tests / rays_per_depth in `out`. */
+int prt_measure_traversal(PrtContext* ctx, uint32_t max_depth, uint32_t seed, uint32_t sample, PrtStats* out);
+int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
+/* Copies the built BVH out (host arrays): nodes n_nodes*16 floats (layout: csrc/bvh.h), tris
+ * n_triangles*12 floats in leaf order.  Either pointer may be NULL.  Works on host-only contexts. */
+int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);
+/* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
+int prt_set_variant(PrtContext* ctx, int variant);
+
+/* ---- host-side data formats either side of the path ------------------------------------------- */
+/* PLY ingest with the subset the reference's Mesh asks tinyply for (src/core/mesh.cpp:79-97,113-144):
+ * vertex x,y,z (+ optional nx,ny,nz), face vertex_indices list; ascii and binary_little_endian.
+ * Missing normals are computed (area-weighted); polygons are fan-triangulated. */
+typedef struct PrtMeshData PrtMeshData;
+int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err, size_t err_len);
+int prt_mesh_create(const float* positions, const float* normals, uint32_t n_vertices, const uint32_t* indices,
+                    uint32_t n_triangles, PrtMeshData** out);
+void prt_mesh_free(PrtMeshData* m);
+uint32_t prt_mesh_vertex_count(const PrtMeshData* m);
+uint32_t prt_mesh_triangle_count(const PrtMeshData* m);
+const float* prt_mesh_positions(const PrtMeshData* m);
+const float* prt_mesh_normals(const PrtMeshData* m);
+const uint32_t* prt_mesh_indices(const PrtMeshData* m);
+int prt_mesh_had_normals(const PrtMeshData* m);
+/* Deterministic longest-edge bisection up to >= target_triangles (SURVEY §8d synthetic inputs). */
+int prt_mesh_refine(PrtMeshData* m, uint32_t target_triangles);
+/* positions = mat * positions, normals = normalize(mat3(inverse-transpose) * normals). */
+int prt_mesh_transform(PrtMeshData* m, const float mat[16], const float inv[16]);
+int prt_mesh_append(PrtMeshData* dst, const PrtMeshData* src);
+
+/* Scene presets (src/core/scene.cpp:62-350) flattened into materials + primitives.
+ * Pass NULL arrays to query counts. */
+int prt_scene_preset(int preset, PrtMaterial* materials, uint32_t* n_materials, PrtPrimitive* primitives,
+                     uint32_t* n_primitives);
+/* Scene::MakeTransform (src/core/scene.cpp:9-17): T * eulerAngleXYZ(radians(deg)) * S and its inverse. */
+void prt_make_transform(const float scale[3], const float euler_deg[3], const float translation[3], float mat[16],
+                        float inv[16]);
+
+/* Offline framebuffer dump (stands in for the GLFW/OpenGL viewer, src/main.cpp:504-527). */
+int prt_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int prt_write_pfm(const char* path, const float* rgb, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

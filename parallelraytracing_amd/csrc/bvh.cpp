@@ -1,0 +1,353 @@
+// bvh.cpp — binned-SAH BVH2 builder (host).  See bvh.h for the node format.
+#include "bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kTraversalCost = 1.0f;
+constexpr float kIntersectCost = 1.5f;
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = FLT_MAX;
+            mx[a] = -FLT_MAX;
+        }
+    }
+    void grow(const float* lo, const float* hi) {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], lo[a]);
+            mx[a] = std::max(mx[a], hi[a]);
+        }
+    }
+    void grow(const Box& b) { grow(b.mn, b.mx); }
+    float half_area() const {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0.0f) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct BuildNode {
+    Box box;
+    int32_t left = -1, right = -1;  // build-node indices
+    uint32_t first = 0, count = 0;
+    uint32_t depth = 0;
+};
+
+struct Builder {
+    const float* verts;
+    uint32_t n;
+    uint32_t max_leaf;
+    std::vector<float> tmin, tmax, cen;  // per-triangle bounds and centroids (3 floats each)
+    std::vector<uint32_t> order;
+    std::vector<BuildNode> nodes;
+    std::atomic<uint32_t> next_node{0};
+
+    uint32_t alloc_pair() { return next_node.fetch_add(2); }
+
+    // Decide and perform the split of node `ni`.  Returns false if it became a leaf.
+    bool split(uint32_t ni, bool force_median) {
+        BuildNode& nd = nodes[ni];
+        const uint32_t first = nd.first, count = nd.count;
+        if (count <= 1) return false;
+        Box cb;
+        cb.reset();
+        for (uint32_t k = first; k < first + count; ++k) {
+            const float* c = &cen[3 * (size_t)order[k]];
+            cb.grow(c, c);
+        }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = FLT_MAX;
+        const float node_area = nd.box.half_area();
+        if (!force_median) {
+            for (int a = 0; a < 3; ++a) {
+                const float ext = cb.mx[a] - cb.mn[a];
+                if (!(ext > 0.0f)) continue;
+                Box bins[kBins];
+                uint32_t cnt[kBins];
+                for (int b = 0; b < kBins; ++b) {
+                    bins[b].reset();
+                    cnt[b] = 0;
+                }
+                const float scale = (float)kBins / ext;
+                for (uint32_t k = first; k < first + count; ++k) {
+                    const uint32_t t = order[k];
+                    int b = (int)((cen[3 * (size_t)t + a] - cb.mn[a]) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bins[b].grow(&tmin[3 * (size_t)t], &tmax[3 * (size_t)t]);
+                    ++cnt[b];
+                }
+                float right_area[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bins[b]);
+                    c += cnt[b];
+                    right_area[b] = acc.half_area();
+                    right_cnt[b] = c;
+                }
+                acc.reset();
+                c = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bins[b]);
+                    c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_bin = b;
+                    }
+                }
+            }
+        }
+        if (best_axis >= 0 && count <= max_leaf && node_area > 0.0f) {
+            const float split_cost = kTraversalCost + kIntersectCost * best_cost / node_area;
+            const float leaf_cost = kIntersectCost * (float)count;
+            if (leaf_cost <= split_cost) return false;
+        }
+        uint32_t mid = 0;
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const float scale = (float)kBins / (cb.mx[a] - cb.mn[a]);
+            const float cmn = cb.mn[a];
+            const int bb = best_bin;
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int b = (int)((cen[3 * (size_t)t + a] - cmn) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= bb;
+            });
+            mid = (uint32_t)(it - (order.begin() + first));
+        }
+        if (mid == 0 || mid == count) {
+            if (count <= max_leaf) return false;
+            // object-median split along the widest centroid axis (also the forced path for deep trees)
+            int a = 0;
+            float ext = cb.mx[0] - cb.mn[0];
+            for (int k = 1; k < 3; ++k)
+                if (cb.mx[k] - cb.mn[k] > ext) {
+                    ext = cb.mx[k] - cb.mn[k];
+                    a = k;
+                }
+            mid = count / 2;
+            std::nth_element(order.begin() + first, order.begin() + first + mid, order.begin() + first + count,
+                             [&](uint32_t x, uint32_t y) {
+                                 const float cx = cen[3 * (size_t)x + a], cy = cen[3 * (size_t)y + a];
+                                 return cx < cy || (cx == cy && x < y);
+                             });
+        }
+        const uint32_t l = alloc_pair();
+        BuildNode& L = nodes[l];
+        BuildNode& R = nodes[l + 1];
+        L.first = first;
+        L.count = mid;
+        R.first = first + mid;
+        R.count = count - mid;
+        L.depth = R.depth = nd.depth + 1;
+        L.box.reset();
+        R.box.reset();
+        for (uint32_t k = L.first; k < L.first + L.count; ++k)
+            L.box.grow(&tmin[3 * (size_t)order[k]], &tmax[3 * (size_t)order[k]]);
+        for (uint32_t k = R.first; k < R.first + R.count; ++k)
+            R.box.grow(&tmin[3 * (size_t)order[k]], &tmax[3 * (size_t)order[k]]);
+        nd.left = (int32_t)l;
+        nd.right = (int32_t)l + 1;
+        return true;
+    }
+
+    void build_subtree(uint32_t root, uint32_t median_depth) {
+        std::vector<uint32_t> stack;
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const uint32_t ni = stack.back();
+            stack.pop_back();
+            if (split(ni, nodes[ni].depth >= median_depth)) {
+                stack.push_back((uint32_t)nodes[ni].right);
+                stack.push_back((uint32_t)nodes[ni].left);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int n_threads, uint32_t max_allowed_depth,
+               BvhBuild* out) {
+    out->nodes.clear();
+    out->order.clear();
+    out->max_depth = 0;
+    out->max_leaf = 0;
+    out->sah_cost = 0.0f;
+    if (n_tris == 0) return true;
+    if (max_leaf_size < 1) max_leaf_size = 1;
+    if (max_leaf_size > 15) max_leaf_size = 15;
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = std::min(n_threads, 32);
+
+    Builder b;
+    b.verts = verts;
+    b.n = n_tris;
+    b.max_leaf = max_leaf_size;
+    b.tmin.resize(3 * (size_t)n_tris);
+    b.tmax.resize(3 * (size_t)n_tris);
+    b.cen.resize(3 * (size_t)n_tris);
+    b.order.resize(n_tris);
+    b.nodes.resize(2 * (size_t)n_tris + 2);
+    BuildNode& root = b.nodes[0];
+    b.next_node = 2;  // slot 1 unused: children are allocated in pairs
+    root.box.reset();
+    for (uint32_t t = 0; t < n_tris; ++t) {
+        const float* v = verts + 9 * (size_t)t;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = std::min(v[a], std::min(v[3 + a], v[6 + a]));
+            const float hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+            b.tmin[3 * (size_t)t + a] = lo;
+            b.tmax[3 * (size_t)t + a] = hi;
+            b.cen[3 * (size_t)t + a] = 0.5f * lo + 0.5f * hi;
+        }
+        b.order[t] = t;
+        root.box.grow(&b.tmin[3 * (size_t)t], &b.tmax[3 * (size_t)t]);
+    }
+    root.first = 0;
+    root.count = n_tris;
+    root.depth = 0;
+
+    // SAH until this depth, then forced object-median splits: bounds the depth by
+    // median_depth + ceil(log2(n)) so the traversal stack (64 entries) can never overflow.
+    const uint32_t median_depth = 40;
+
+    // Phase 1 (serial): split the top of the tree until there are enough independent subtrees.
+    std::vector<uint32_t> frontier{0};
+    const size_t want_tasks = (size_t)n_threads * 8;
+    const uint32_t min_task = 4096;
+    while (n_threads > 1 && frontier.size() < want_tasks) {
+        size_t big = frontier.size();
+        uint32_t big_count = min_task;
+        for (size_t i = 0; i < frontier.size(); ++i)
+            if (b.nodes[frontier[i]].count > big_count) {
+                big_count = b.nodes[frontier[i]].count;
+                big = i;
+            }
+        if (big == frontier.size()) break;
+        const uint32_t ni = frontier[big];
+        frontier.erase(frontier.begin() + (long)big);
+        if (b.split(ni, b.nodes[ni].depth >= median_depth)) {
+            frontier.push_back((uint32_t)b.nodes[ni].left);
+            frontier.push_back((uint32_t)b.nodes[ni].right);
+        }
+    }
+    // Phase 2 (parallel): each remaining subtree works on its own disjoint slice of order[].
+    if (n_threads > 1 && frontier.size() > 1) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&]() {
+                while (true) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= frontier.size()) break;
+                    b.build_subtree(frontier[i], median_depth);
+                }
+            });
+        for (auto& t : th) t.join();
+    } else {
+        for (uint32_t ni : frontier) b.build_subtree(ni, median_depth);
+    }
+
+    // Flatten: internal nodes renumbered in depth-first preorder; triangle slots are order[] as is.
+    struct Item {
+        uint32_t build, dev;
+    };
+    auto is_leaf = [&](uint32_t ni) { return b.nodes[ni].left < 0; };
+    auto leaf_ref = [&](uint32_t ni) -> int32_t {
+        const BuildNode& nd = b.nodes[ni];
+        return (int32_t) ~((nd.first << 4) | nd.count);
+    };
+    uint32_t n_internal = 0;
+    {
+        std::vector<uint32_t> st{0};
+        while (!st.empty()) {
+            uint32_t ni = st.back();
+            st.pop_back();
+            if (is_leaf(ni)) continue;
+            ++n_internal;
+            st.push_back((uint32_t)b.nodes[ni].right);
+            st.push_back((uint32_t)b.nodes[ni].left);
+        }
+    }
+    if (n_tris >= (1u << 27)) return false;
+    double sah = 0.0;
+    const float root_area = std::max(root.box.half_area(), 1e-30f);
+    if (is_leaf(0)) {
+        // single-leaf tree: one device node whose left child is the leaf and whose right child is empty
+        out->nodes.assign(16, 0.0f);
+        float* q = out->nodes.data();
+        const Box& bx = root.box;
+        q[0] = bx.mn[0]; q[1] = bx.mn[1]; q[2] = bx.mn[2]; q[3] = bx.mx[0]; q[4] = bx.mx[1]; q[5] = bx.mx[2];
+        // right box: degenerate point far away
+        for (int k = 6; k < 12; ++k) q[k] = 3.0e38f;
+        int32_t l = leaf_ref(0), r = ~0;
+        memcpy(&q[12], &l, 4);
+        memcpy(&q[13], &r, 4);
+        out->max_depth = 1;
+        out->max_leaf = root.count;
+        sah = kIntersectCost * root.count;
+    } else {
+        out->nodes.assign(16 * (size_t)n_internal, 0.0f);
+        std::vector<Item> st;
+        st.push_back({0, 0});
+        uint32_t next_dev = 1;
+        while (!st.empty()) {
+            const Item it = st.back();
+            st.pop_back();
+            const BuildNode& nd = b.nodes[it.build];
+            const uint32_t li = (uint32_t)nd.left, ri = (uint32_t)nd.right;
+            const Box& lb = b.nodes[li].box;
+            const Box& rb = b.nodes[ri].box;
+            float* q = &out->nodes[16 * (size_t)it.dev];
+            q[0] = lb.mn[0]; q[1] = lb.mn[1]; q[2] = lb.mn[2]; q[3] = lb.mx[0]; q[4] = lb.mx[1]; q[5] = lb.mx[2];
+            q[6] = rb.mn[0]; q[7] = rb.mn[1]; q[8] = rb.mn[2]; q[9] = rb.mx[0]; q[10] = rb.mx[1]; q[11] = rb.mx[2];
+            int32_t lref, rref;
+            // preorder: the left subtree's internal nodes directly follow this node
+            uint32_t ldev = 0, rdev = 0;
+            if (is_leaf(li)) {
+                lref = leaf_ref(li);
+            } else {
+                ldev = next_dev++;
+                lref = (int32_t)ldev;
+            }
+            if (is_leaf(ri)) {
+                rref = leaf_ref(ri);
+            } else {
+                rdev = next_dev++;
+                rref = (int32_t)rdev;
+            }
+            memcpy(&q[12], &lref, 4);
+            memcpy(&q[13], &rref, 4);
+            sah += kTraversalCost * nd.box.half_area() / root_area;
+            for (uint32_t ci : {li, ri}) {
+                const BuildNode& c = b.nodes[ci];
+                if (is_leaf(ci)) {
+                    out->max_depth = std::max(out->max_depth, c.depth + 1);
+                    out->max_leaf = std::max(out->max_leaf, c.count);
+                    sah += kIntersectCost * c.count * c.box.half_area() / root_area;
+                }
+            }
+            if (!is_leaf(ri)) st.push_back({ri, rdev});
+            if (!is_leaf(li)) st.push_back({li, ldev});
+        }
+    }
+    out->sah_cost = (float)sah;
+    out->order = std::move(b.order);
+    return out->max_depth <= max_allowed_depth;
+}

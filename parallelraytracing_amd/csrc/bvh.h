@@ -1,0 +1,29 @@
+// bvh.h — host-side BVH2 builder (binned SAH) for the traversal kernel in prt_kernels.hip.
+//
+// The reference has NO acceleration structure (closest hit is a linear scan,
+// src/core/primitive.cpp:26-49; "add a simple BVH" is on its roadmap, wavefront.md:88-90); only the
+// building blocks exist (AABB::Union / MaxExtent, src/core/geometry.h:155-205).  The BVH below is this
+// project's own; results are BVH-independent by construction (see k_intersect).
+//
+// Device node = 64 B = 4 x float4:
+//   q0 = (Lmin.x, Lmin.y, Lmin.z, Lmax.x)   q1 = (Lmax.y, Lmax.z, Rmin.x, Rmin.y)
+//   q2 = (Rmin.z, Rmax.x, Rmax.y, Rmax.z)   q3 = (left, right, 0, 0) as int bits
+// child ref >= 0: internal node index; < 0: leaf, ~ref = (first_triangle_slot << 4) | count (count 0..15).
+// Boxes are the exact fp32 bounds of the vertices (padding is applied per ray by the kernel).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+struct BvhBuild {
+    std::vector<float> nodes;     // 16 floats per node
+    std::vector<uint32_t> order;  // leaf slot -> input triangle index
+    uint32_t max_depth = 0;       // edges on the longest root-to-leaf path (+1 for the root node itself)
+    uint32_t max_leaf = 0;
+    float sah_cost = 0.0f;
+};
+
+// verts: n_tris * 9 floats (P0,P1,P2).  max_leaf_size <= 15.  n_threads <= 0: hardware concurrency.
+// Returns false if the tree would be deeper than max_allowed_depth.
+bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int n_threads, uint32_t max_allowed_depth,
+               BvhBuild* out);

@@ -1,0 +1,837 @@
+// prt_api.cpp — implementation of the C-ABI in include/prt.h on top of the HIP kernels.
+//
+// Host-side mirror of what the reference's CudaWavefrontRenderer does around its kernels
+// (src/backend/cuda_wavefront/renderer.cu:351-547: Init / ProgressiveRender / SetCamera / Allocate*),
+// re-designed: flat SoA scene upload in one piece (no per-object cudaMalloc, soa.cpp:60-61,86-87),
+// dense double-buffered ray records, device-side counters (no 1-thread reset kernels,
+// renderer.cu:399-414), no host synchronisation inside a sample.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/prt.h"
+#include "bvh.h"
+#include "prt_kernels.h"
+
+namespace {
+
+constexpr float kPadCoeff = 1.0f / 262144.0f;  // 2^-18, see traverse() in prt_kernels.hip
+constexpr uint32_t kMaxLeaf = 4;
+constexpr uint32_t kMaxStack = 64;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;  // 0 raygen, 1 intersect, 2 shade, 3 accumulate
+};
+
+}  // namespace
+
+struct PrtContext {
+    int device = -1;
+    bool has_device = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- scene ----
+    bool has_scene = false;
+    std::vector<PrtMaterial> materials;
+    std::vector<DevPrim> prims;
+    BvhBuild bvh;
+    std::vector<float> tri_records;   // 12 floats per triangle, leaf order
+    std::vector<float> nrm_records;   // 12 floats per triangle, leaf order
+    PrtBvhInfo bvh_info{};
+    DevScene dsc{};
+    void* d_prims = nullptr;
+    void* d_mat_rgbs = nullptr;
+    void* d_mat_type = nullptr;
+    void* d_nodes = nullptr;
+    void* d_tris = nullptr;
+    void* d_nrms = nullptr;
+
+    // ---- camera ----
+    bool has_camera = false;
+    DevCamera cam{};
+
+    // ---- film / partition ----
+    bool has_film = false;
+    PrtTileMap tm{};
+    uint32_t valid_local = 0;  // pixels of this rank inside the image
+    float4* d_film_local = nullptr;
+
+    // ---- path state ----
+    uint32_t S = 1;
+    uint64_t cap_paths = 0;
+    PrtRayBuf rb[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    uint32_t* d_hit = nullptr;
+    float4* d_rad = nullptr;
+    uint32_t* d_counts = nullptr;             // PRT_MAX_DEPTH + 1
+    unsigned long long* d_ray_stats = nullptr;  // PRT_MAX_DEPTH
+    unsigned long long* d_trav_stats = nullptr; // 3
+
+    // ---- scratch for the function-level entry points ----
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    // ---- stats ----
+    bool timing = false;
+    std::vector<EventPair> events;
+    std::vector<EventPair> event_pool;
+    PrtStats stats{};
+    uint64_t dead_paths = 0;
+    int variant = 0;
+};
+
+namespace {
+
+int fail(PrtContext* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHECK(c, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail((c), PRT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int need_device(PrtContext* c) {
+    if (!c) return PRT_ERR_INVALID;
+    if (!c->has_device)
+        return fail(c, PRT_ERR_NO_DEVICE,
+                    "no HIP device bound to this context: the MI355X kernels are the only compute path (no CPU fallback)");
+    return PRT_OK;
+}
+
+void free_dev(void*& p) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+template <class T>
+void free_dev(T*& p) {
+    if (p) {
+        (void)hipFree((void*)p);
+        p = nullptr;
+    }
+}
+
+void free_path_state(PrtContext* c) {
+    for (int i = 0; i < 2; ++i) {
+        free_dev(c->rb[i].o);
+        free_dev(c->rb[i].d);
+        free_dev(c->rb[i].t);
+    }
+    free_dev(c->d_hit);
+    free_dev(c->d_rad);
+    c->cap_paths = 0;
+}
+
+int ensure_path_state(PrtContext* c, uint64_t n_paths) {
+    if (n_paths <= c->cap_paths) return PRT_OK;
+    free_path_state(c);
+    const uint64_t n = std::max<uint64_t>(n_paths, 256);
+    for (int i = 0; i < 2; ++i) {
+        HIPCHECK(c, hipMalloc((void**)&c->rb[i].o, n * sizeof(float4)));
+        HIPCHECK(c, hipMalloc((void**)&c->rb[i].d, n * sizeof(float4)));
+        HIPCHECK(c, hipMalloc((void**)&c->rb[i].t, n * sizeof(float4)));
+    }
+    HIPCHECK(c, hipMalloc((void**)&c->d_hit, n * sizeof(uint32_t)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_rad, n * sizeof(float4)));
+    c->cap_paths = n;
+    return PRT_OK;
+}
+
+int ensure_counters(PrtContext* c) {
+    if (c->d_counts) return PRT_OK;
+    HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 4 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
+    return PRT_OK;
+}
+
+int ensure_scratch(PrtContext* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return PRT_OK;
+    free_dev(c->d_scratch);
+    c->scratch_bytes = 0;
+    HIPCHECK(c, hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+    return PRT_OK;
+}
+
+void free_scene(PrtContext* c) {
+    free_dev(c->d_prims);
+    free_dev(c->d_mat_rgbs);
+    free_dev(c->d_mat_type);
+    free_dev(c->d_nodes);
+    free_dev(c->d_tris);
+    free_dev(c->d_nrms);
+    c->has_scene = false;
+}
+
+// timing helpers ----------------------------------------------------------------------------------
+int begin_event(PrtContext* c, int kind, EventPair* ep) {
+    if (!c->timing) return PRT_OK;
+    if (!c->event_pool.empty()) {
+        *ep = c->event_pool.back();
+        c->event_pool.pop_back();
+    } else {
+        HIPCHECK(c, hipEventCreate(&ep->a));
+        HIPCHECK(c, hipEventCreate(&ep->b));
+    }
+    ep->kind = kind;
+    HIPCHECK(c, hipEventRecord(ep->a, c->stream));
+    return PRT_OK;
+}
+int end_event(PrtContext* c, EventPair* ep) {
+    if (!c->timing) return PRT_OK;
+    HIPCHECK(c, hipEventRecord(ep->b, c->stream));
+    c->events.push_back(*ep);
+    return PRT_OK;
+}
+int drain_events(PrtContext* c) {
+    for (EventPair& ep : c->events) {
+        float ms = 0.0f;
+        HIPCHECK(c, hipEventSynchronize(ep.b));
+        HIPCHECK(c, hipEventElapsedTime(&ms, ep.a, ep.b));
+        switch (ep.kind) {
+            case 0: c->stats.raygen_ms += ms; break;
+            case 1: c->stats.intersect_ms += ms; break;
+            case 2: c->stats.shade_ms += ms; break;
+            default: c->stats.accumulate_ms += ms; break;
+        }
+        c->event_pool.push_back(ep);
+    }
+    c->events.clear();
+    return PRT_OK;
+}
+
+void to_dev_mat(const float* m16, float* m12) {
+    for (int col = 0; col < 4; ++col)
+        for (int r = 0; r < 3; ++r) m12[col * 3 + r] = m16[col * 4 + r];
+}
+
+// glm-order helpers for the camera basis (Camera::Camera, src/core/camera.h:10-16)
+f3 h_normalize(f3 v) {
+    const float d = (v.x * v.x + v.y * v.y) + v.z * v.z;
+    const float s = 1.0f / std::sqrt(d);
+    return f3{v.x * s, v.y * s, v.z * s};
+}
+f3 h_cross(f3 a, f3 b) { return f3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+
+// One batch of S_cur samples: raygen -> (intersect, shade) x max_depth -> [accumulate]
+int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, uint32_t first_sample, bool accumulate,
+              unsigned long long* trav_stats) {
+    const uint64_t n_paths64 = (uint64_t)S_cur * c->tm.n_pix_local;
+    if (n_paths64 == 0) return PRT_OK;
+    if (n_paths64 > 0xFFFFFF00ull) return fail(c, PRT_ERR_INVALID, "too many paths in flight");
+    const uint32_t n_paths = (uint32_t)n_paths64;
+    int rc = ensure_path_state(c, n_paths);
+    if (rc) return rc;
+    const int stack_depth = c->bvh.max_depth <= 32 ? 32 : 64;
+    EventPair ep{};
+    if ((rc = begin_event(c, 0, &ep))) return rc;
+    prt_launch_raygen(c->stream, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts, max_depth);
+    if ((rc = end_event(c, &ep))) return rc;
+    for (uint32_t d = 0; d < max_depth; ++d) {
+        const PrtRayBuf& in = c->rb[d & 1];
+        const PrtRayBuf& out = c->rb[(d + 1) & 1];
+        if ((rc = begin_event(c, 1, &ep))) return rc;
+        prt_launch_intersect(c->stream, c->dsc, in, c->d_hit, c->d_counts + d, n_paths, stack_depth, c->variant,
+                             trav_stats);
+        if ((rc = end_event(c, &ep))) return rc;
+        ++c->stats.intersect_launches;
+        if ((rc = begin_event(c, 2, &ep))) return rc;
+        prt_launch_shade(c->stream, c->dsc, in, c->d_hit, out, c->d_rad, c->d_counts, d, max_depth, n_paths);
+        if ((rc = end_event(c, &ep))) return rc;
+    }
+    if (accumulate) {
+        if ((rc = begin_event(c, 3, &ep))) return rc;
+        prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, c->d_counts, max_depth,
+                              c->d_ray_stats);
+        if ((rc = end_event(c, &ep))) return rc;
+        c->dead_paths += (uint64_t)S_cur * (c->tm.n_pix_local - c->valid_local);
+        c->stats.samples += S_cur;
+    }
+    HIPCHECK(c, hipGetLastError());
+    return PRT_OK;
+}
+
+int check_ready(PrtContext* c) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (!c->has_camera) return fail(c, PRT_ERR_INVALID, "prt_set_camera has not been called");
+    if (!c->has_film) return fail(c, PRT_ERR_INVALID, "prt_set_film has not been called");
+    return PRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int prt_version(void) { return PRT_VERSION; }
+
+int prt_create(int device_id, PrtContext** out) {
+    if (!out) return PRT_ERR_INVALID;
+    PrtContext* c = new PrtContext();
+    *out = c;
+    c->device = device_id;
+    if (device_id < 0) return PRT_OK;  // host-only context
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(c, PRT_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id >= n) return fail(c, PRT_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_id, n);
+    HIPCHECK(c, hipSetDevice(device_id));
+    HIPCHECK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    c->has_device = true;
+    return PRT_OK;
+}
+
+void prt_destroy(PrtContext* c) {
+    if (!c) return;
+    if (c->has_device) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        free_scene(c);
+        free_path_state(c);
+        free_dev(c->d_film_local);
+        free_dev(c->d_counts);
+        free_dev(c->d_ray_stats);
+        free_dev(c->d_trav_stats);
+        free_dev(c->d_scratch);
+        for (EventPair& ep : c->events) {
+            (void)hipEventDestroy(ep.a);
+            (void)hipEventDestroy(ep.b);
+        }
+        for (EventPair& ep : c->event_pool) {
+            (void)hipEventDestroy(ep.a);
+            (void)hipEventDestroy(ep.b);
+        }
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
+    delete c;
+}
+
+const char* prt_last_error(const PrtContext* c) { return c ? c->err.c_str() : "null context"; }
+
+int prt_set_stream(PrtContext* c, void* hip_stream) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PRT_OK;
+}
+
+int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
+    if (!c || !s) return PRT_ERR_INVALID;
+    if ((s->n_materials && !s->materials) || (s->n_primitives && !s->primitives) || (s->n_meshes && !s->meshes))
+        return fail(c, PRT_ERR_INVALID, "null array in scene description");
+    // ---- validate + flatten (host) ----
+    c->materials.assign(s->materials, s->materials + s->n_materials);
+    c->prims.clear();
+    for (uint32_t i = 0; i < s->n_primitives; ++i) {
+        const PrtPrimitive& p = s->primitives[i];
+        if (p.shape_type != PRT_SHAPE_CIRCLE && p.shape_type != PRT_SHAPE_QUAD)
+            return fail(c, PRT_ERR_INVALID, "primitive %u: analytic shapes are CIRCLE or QUAD (triangles come as meshes)", i);
+        if (p.material_id >= s->n_materials) return fail(c, PRT_ERR_INVALID, "primitive %u: material out of range", i);
+        DevPrim d;
+        d.shape_type = p.shape_type;
+        d.p0 = p.shape_param[0];
+        d.p1 = p.shape_param[1];
+        d.material = p.material_id;
+        to_dev_mat(p.mat, d.mat);
+        to_dev_mat(p.inv, d.inv);
+        c->prims.push_back(d);
+    }
+    uint64_t n_tris = 0;
+    for (uint32_t m = 0; m < s->n_meshes; ++m) {
+        const PrtMesh& me = s->meshes[m];
+        if (me.n_triangles && (!me.positions || !me.normals || !me.indices))
+            return fail(c, PRT_ERR_INVALID, "mesh %u: positions, normals and indices are required", m);
+        if (me.material_id >= s->n_materials) return fail(c, PRT_ERR_INVALID, "mesh %u: material out of range", m);
+        n_tris += me.n_triangles;
+    }
+    if (n_tris >= (1ull << 27)) return fail(c, PRT_ERR_INVALID, "too many triangles");
+    std::vector<float> verts(9 * (size_t)n_tris);
+    std::vector<float> norms(9 * (size_t)n_tris);
+    std::vector<uint32_t> tri_mat((size_t)n_tris);
+    float extent = 0.0f;
+    {
+        size_t t = 0;
+        for (uint32_t m = 0; m < s->n_meshes; ++m) {
+            const PrtMesh& me = s->meshes[m];
+            for (uint32_t k = 0; k < me.n_triangles; ++k, ++t) {
+                for (int v = 0; v < 3; ++v) {
+                    const uint32_t vi = me.indices[3 * (size_t)k + v];
+                    if (vi >= me.n_vertices) return fail(c, PRT_ERR_INVALID, "mesh %u: vertex index out of range", m);
+                    for (int a = 0; a < 3; ++a) {
+                        const float pv = me.positions[3 * (size_t)vi + a];
+                        if (!std::isfinite(pv)) return fail(c, PRT_ERR_INVALID, "mesh %u: non-finite vertex", m);
+                        verts[9 * t + 3 * v + a] = pv;
+                        norms[9 * t + 3 * v + a] = me.normals[3 * (size_t)vi + a];
+                        extent = std::max(extent, std::fabs(pv));
+                    }
+                }
+                tri_mat[t] = me.material_id;
+            }
+        }
+    }
+    if (!bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh))
+        return fail(c, PRT_ERR_INVALID, "BVH deeper than the traversal stack (%u > %u)", c->bvh.max_depth, kMaxStack);
+    const uint32_t n_prims = (uint32_t)c->prims.size();
+    c->tri_records.assign(12 * (size_t)n_tris, 0.0f);
+    c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
+    for (size_t slot = 0; slot < (size_t)n_tris; ++slot) {
+        const uint32_t t = c->bvh.order[slot];
+        float* r = &c->tri_records[12 * slot];
+        float* q = &c->nrm_records[12 * slot];
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) {
+                r[4 * v + a] = verts[9 * (size_t)t + 3 * v + a];
+                q[4 * v + a] = norms[9 * (size_t)t + 3 * v + a];
+            }
+        const uint32_t prim = n_prims + t;  // global primitive index: analytic first, then triangles in input order
+        memcpy(&r[3], &prim, 4);
+        memcpy(&r[7], &tri_mat[t], 4);
+    }
+    PrtBvhInfo& bi = c->bvh_info;
+    bi.n_nodes = (uint32_t)(c->bvh.nodes.size() / 16);
+    bi.n_triangles = (uint32_t)n_tris;
+    bi.max_depth = c->bvh.max_depth;
+    bi.max_leaf_size = c->bvh.max_leaf;
+    bi.sah_cost = c->bvh.sah_cost;
+    bi.pad_abs = kPadCoeff;
+    bi.node_bytes = (uint64_t)c->bvh.nodes.size() * 4;
+    bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
+
+    DevScene& d = c->dsc;
+    memset(&d, 0, sizeof(d));
+    d.n_prims = n_prims;
+    d.n_nodes = bi.n_nodes;
+    d.n_tris = (uint32_t)n_tris;
+    d.pad = kPadCoeff;
+    d.extent = extent;
+    memcpy(d.sky, s->sky, sizeof(d.sky));
+    c->has_scene = true;
+    if (!c->has_device) return PRT_OK;  // host-only context: BVH built, nothing to upload
+
+    // ---- upload ----
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    c->has_scene = true;
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    std::vector<float> rgbs(4 * c->materials.size());
+    std::vector<uint32_t> mtype(c->materials.size());
+    for (size_t i = 0; i < c->materials.size(); ++i) {
+        rgbs[4 * i + 0] = c->materials[i].rgb[0];
+        rgbs[4 * i + 1] = c->materials[i].rgb[1];
+        rgbs[4 * i + 2] = c->materials[i].rgb[2];
+        rgbs[4 * i + 3] = c->materials[i].scalar;
+        mtype[i] = c->materials[i].type;
+    }
+    HIPCHECK(c, upload(&c->d_prims, c->prims.data(), c->prims.size() * sizeof(DevPrim)));
+    HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
+    HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
+    HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
+    HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
+    HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
+    d.prims = (const DevPrim*)c->d_prims;
+    d.mat_rgbs = (const float4*)c->d_mat_rgbs;
+    d.mat_type = (const uint32_t*)c->d_mat_type;
+    d.nodes = (const float4*)c->d_nodes;
+    d.tris = (const float4*)c->d_tris;
+    d.tri_normals = (const float4*)c->d_nrms;
+    return ensure_counters(c);
+}
+
+int prt_set_camera(PrtContext* c, const PrtCameraDesc* cam) {
+    if (!c || !cam) return PRT_ERR_INVALID;
+    if (!(cam->width > 0.0f) || !(cam->height > 0.0f)) return fail(c, PRT_ERR_INVALID, "camera width/height must be > 0");
+    DevCamera& k = c->cam;
+    k.pos = f3{cam->position[0], cam->position[1], cam->position[2]};
+    k.front = h_normalize(f3{cam->front[0], cam->front[1], cam->front[2]});
+    k.right = h_normalize(h_cross(k.front, f3{0.0f, 1.0f, 0.0f}));
+    k.up = h_normalize(h_cross(k.right, k.front));
+    k.W = cam->width;
+    k.H = cam->height;
+    k.tan_fov_y = tanf(0.5f);  // src/core/camera.h:111
+    c->has_camera = true;
+    return PRT_OK;
+}
+
+int prt_set_film(PrtContext* c, uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
+    if (!c) return PRT_ERR_INVALID;
+    if (width == 0 || height == 0 || world == 0 || rank >= world)
+        return fail(c, PRT_ERR_INVALID, "bad film size or partition (%ux%u, rank %u of %u)", width, height, rank, world);
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(c, PRT_ERR_INVALID, "film too large");
+    PrtTileMap& tm = c->tm;
+    tm.W = width;
+    tm.H = height;
+    tm.tiles_x = (width + 7) / 8;
+    tm.tiles_y = (height + 7) / 8;
+    tm.rank = rank;
+    tm.world = world;
+    const uint32_t tiles = tm.tiles_x * tm.tiles_y;
+    tm.n_tiles_local = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+    tm.n_pix_local = tm.n_tiles_local * 64;
+    tm.stride = ((tiles + world - 1) / world) * 64;
+    uint32_t valid = 0;
+    for (uint32_t lt = 0; lt < tm.n_tiles_local; ++lt) {
+        const uint32_t gt = lt * world + rank;
+        const uint32_t tx = gt % tm.tiles_x, ty = gt / tm.tiles_x;
+        const uint32_t w = std::min(8u, width - tx * 8), h = std::min(8u, height - ty * 8);
+        valid += w * h;
+    }
+    c->valid_local = valid;
+    c->has_film = true;
+    if (!c->has_device) return PRT_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_film_local);
+    HIPCHECK(c, hipMalloc((void**)&c->d_film_local, std::max<size_t>((size_t)tm.stride, 64) * sizeof(float4)));
+    int rc = ensure_counters(c);
+    if (rc) return rc;
+    return prt_film_clear(c);
+}
+
+int prt_film_clear(PrtContext* c) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film) return fail(c, PRT_ERR_INVALID, "prt_set_film has not been called");
+    HIPCHECK(c, hipMemsetAsync(c->d_film_local, 0, std::max<size_t>((size_t)c->tm.stride, 64) * sizeof(float4), c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_set_samples_in_flight(PrtContext* c, uint32_t n) {
+    if (!c || n == 0 || n > 1024) return fail(c, PRT_ERR_INVALID, "samples in flight must be 1..1024");
+    c->S = n;
+    return PRT_OK;
+}
+
+int prt_render_async(PrtContext* c, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (max_depth == 0 || max_depth > PRT_MAX_DEPTH) return fail(c, PRT_ERR_INVALID, "max_depth must be 1..%d", PRT_MAX_DEPTH);
+    HIPCHECK(c, hipSetDevice(c->device));
+    uint32_t done = 0;
+    while (done < spp) {
+        const uint32_t S_cur = std::min(c->S, spp - done);
+        rc = run_batch(c, S_cur, max_depth, seed, first_sample + done, true, nullptr);
+        if (rc) return rc;
+        done += S_cur;
+    }
+    return PRT_OK;
+}
+
+int prt_synchronize(PrtContext* c) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_render(PrtContext* c, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample) {
+    int rc = prt_render_async(c, spp, max_depth, seed, first_sample);
+    if (rc) return rc;
+    return prt_synchronize(c);
+}
+
+int prt_film_local(PrtContext* c, void** d_ptr, uint64_t* n_floats) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film) return fail(c, PRT_ERR_INVALID, "prt_set_film has not been called");
+    if (d_ptr) *d_ptr = c->d_film_local;
+    if (n_floats) *n_floats = (uint64_t)c->tm.stride * 4;
+    return PRT_OK;
+}
+
+int prt_film_resolve(PrtContext* c, const void* d_gathered, uint32_t world, void* d_rgb, void* d_weight) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film || !d_gathered || !d_rgb || !d_weight || world != c->tm.world)
+        return fail(c, PRT_ERR_INVALID, "bad arguments to prt_film_resolve");
+    prt_launch_resolve(c->stream, (const float4*)d_gathered, world, c->tm.stride, c->tm.W, c->tm.H, (float*)d_rgb,
+                       (float*)d_weight);
+    HIPCHECK(c, hipGetLastError());
+    return PRT_OK;
+}
+
+int prt_film_tonemap(PrtContext* c, const void* d_rgb, const void* d_weight, float exposure, float gamma, void* d_rgba8) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film || !d_rgb || !d_weight || !d_rgba8) return fail(c, PRT_ERR_INVALID, "bad arguments to prt_film_tonemap");
+    prt_launch_tonemap(c->stream, (const float*)d_rgb, (const float*)d_weight, c->tm.W * c->tm.H, exposure, 1.0f / gamma,
+                       (uint8_t*)d_rgba8);
+    HIPCHECK(c, hipGetLastError());
+    return PRT_OK;
+}
+
+// Builds [world][stride] with only this rank's payload filled, resolves it, and leaves rgb / weight in scratch.
+static int resolve_own(PrtContext* c, float** d_rgb, float** d_w, uint8_t** d_rgba) {
+    const PrtTileMap& tm = c->tm;
+    const size_t npix = (size_t)tm.W * tm.H;
+    const size_t gathered = (size_t)tm.world * tm.stride * sizeof(float4);
+    const size_t off_rgb = (gathered + 255) & ~(size_t)255;
+    const size_t off_w = off_rgb + ((npix * 12 + 255) & ~(size_t)255);
+    const size_t off_b = off_w + ((npix * 4 + 255) & ~(size_t)255);
+    int rc = ensure_scratch(c, off_b + npix * 4);
+    if (rc) return rc;
+    char* base = (char*)c->d_scratch;
+    HIPCHECK(c, hipMemsetAsync(base, 0, gathered, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(base + (size_t)tm.rank * tm.stride * sizeof(float4), c->d_film_local,
+                               (size_t)tm.stride * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    *d_rgb = (float*)(base + off_rgb);
+    *d_w = (float*)(base + off_w);
+    *d_rgba = (uint8_t*)(base + off_b);
+    prt_launch_resolve(c->stream, (const float4*)base, tm.world, tm.stride, tm.W, tm.H, *d_rgb, *d_w);
+    HIPCHECK(c, hipGetLastError());
+    return PRT_OK;
+}
+
+int prt_film_read(PrtContext* c, float* rgb_sum, float* weight) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film) return fail(c, PRT_ERR_INVALID, "prt_set_film has not been called");
+    float *d_rgb, *d_w;
+    uint8_t* d_b;
+    if ((rc = resolve_own(c, &d_rgb, &d_w, &d_b))) return rc;
+    const size_t npix = (size_t)c->tm.W * c->tm.H;
+    if (rgb_sum) HIPCHECK(c, hipMemcpyAsync(rgb_sum, d_rgb, npix * 12, hipMemcpyDeviceToHost, c->stream));
+    if (weight) HIPCHECK(c, hipMemcpyAsync(weight, d_w, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_film_display(PrtContext* c, float exposure, float gamma, uint8_t* rgba8) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_film || !rgba8) return fail(c, PRT_ERR_INVALID, "bad arguments to prt_film_display");
+    float *d_rgb, *d_w;
+    uint8_t* d_b;
+    if ((rc = resolve_own(c, &d_rgb, &d_w, &d_b))) return rc;
+    const uint32_t npix = c->tm.W * c->tm.H;
+    prt_launch_tonemap(c->stream, d_rgb, d_w, npix, exposure, 1.0f / gamma, d_b);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(rgba8, d_b, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+// ---- function-level entry points ------------------------------------------------------------------
+int prt_camera_rays(PrtContext* c, uint32_t n, const float* px, const float* py, float* origins, float* dirs) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_camera) return fail(c, PRT_ERR_INVALID, "prt_set_camera has not been called");
+    if (n == 0) return PRT_OK;
+    if (!px || !py || !origins || !dirs) return fail(c, PRT_ERR_INVALID, "null array");
+    const size_t b1 = (size_t)n * 4, b3 = (size_t)n * 12;
+    if ((rc = ensure_scratch(c, 2 * b1 + 2 * b3))) return rc;
+    char* base = (char*)c->d_scratch;
+    float* d_px = (float*)base;
+    float* d_py = (float*)(base + b1);
+    float* d_o = (float*)(base + 2 * b1);
+    float* d_d = (float*)(base + 2 * b1 + b3);
+    HIPCHECK(c, hipMemcpyAsync(d_px, px, b1, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(d_py, py, b1, hipMemcpyHostToDevice, c->stream));
+    prt_launch_camera_rays(c->stream, c->cam, n, d_px, d_py, d_o, d_d);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(origins, d_o, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dirs, d_d, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float* dirs, PrtHit* hits) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (n == 0) return PRT_OK;
+    if (!origins || !dirs || !hits) return fail(c, PRT_ERR_INVALID, "null array");
+    if ((rc = ensure_path_state(c, n))) return rc;
+    if ((rc = ensure_counters(c))) return rc;
+    const size_t b3 = (size_t)n * 12;
+    const size_t bh = (size_t)n * sizeof(PrtHit);
+    if ((rc = ensure_scratch(c, 2 * b3 + bh + 64))) return rc;
+    char* base = (char*)c->d_scratch;
+    float* d_o = (float*)base;
+    float* d_d = (float*)(base + b3);
+    PrtHit* d_h = (PrtHit*)(base + ((2 * b3 + 15) & ~(size_t)15));
+    HIPCHECK(c, hipMemcpyAsync(d_o, origins, b3, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(d_d, dirs, b3, hipMemcpyHostToDevice, c->stream));
+    uint32_t* cnt = c->d_counts + PRT_MAX_DEPTH + 1;  // a counter slot the render loop never uses
+    prt_launch_pack_rays(c->stream, n, d_o, d_d, c->rb[0], cnt);
+    const int stack_depth = c->bvh.max_depth <= 32 ? 32 : 64;
+    prt_launch_intersect(c->stream, c->dsc, c->rb[0], c->d_hit, cnt, n, stack_depth, c->variant, nullptr);
+    prt_launch_hit_records(c->stream, c->dsc, n, c->rb[0], c->d_hit, d_h);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(hits, d_h, bh, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_scatter(PrtContext* c, uint32_t n, const float* in_dirs, const PrtHit* hits, uint32_t* rng_state,
+                uint32_t* scattered, float* attenuation, float* emitted, float* out_origins, float* out_dirs) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (n == 0) return PRT_OK;
+    if (!in_dirs || !hits || !rng_state || !scattered || !attenuation || !emitted || !out_origins || !out_dirs)
+        return fail(c, PRT_ERR_INVALID, "null array");
+    for (uint32_t i = 0; i < n; ++i)
+        if (hits[i].material_id >= c->materials.size()) return fail(c, PRT_ERR_INVALID, "hit %u: material out of range", i);
+    const size_t b3 = (size_t)n * 12, b1 = (size_t)n * 4, bh = (size_t)n * sizeof(PrtHit);
+    if ((rc = ensure_scratch(c, 5 * b3 + 2 * b1 + bh + 64))) return rc;
+    char* base = (char*)c->d_scratch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base + off;
+        off += (bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    PrtHit* d_h = (PrtHit*)take(bh);
+    float* d_in = (float*)take(b3);
+    uint32_t* d_rng = (uint32_t*)take(b1);
+    uint32_t* d_sc = (uint32_t*)take(b1);
+    float* d_at = (float*)take(b3);
+    float* d_em = (float*)take(b3);
+    float* d_oo = (float*)take(b3);
+    float* d_od = (float*)take(b3);
+    HIPCHECK(c, hipMemcpyAsync(d_h, hits, bh, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(d_in, in_dirs, b3, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(d_rng, rng_state, b1, hipMemcpyHostToDevice, c->stream));
+    prt_launch_scatter_test(c->stream, c->dsc, n, d_in, d_h, d_rng, d_sc, d_at, d_em, d_oo, d_od);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(rng_state, d_rng, b1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(scattered, d_sc, b1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(attenuation, d_at, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(emitted, d_em, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(out_origins, d_oo, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(out_dirs, d_od, b3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+int prt_enable_timing(PrtContext* c, int on) {
+    if (!c) return PRT_ERR_INVALID;
+    c->timing = on != 0;
+    return PRT_OK;
+}
+
+int prt_get_stats(PrtContext* c, PrtStats* out) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!out) return PRT_ERR_INVALID;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = drain_events(c))) return rc;
+    PrtStats s = c->stats;
+    if (c->d_ray_stats) {
+        unsigned long long h[PRT_MAX_DEPTH];
+        HIPCHECK(c, hipMemcpy(h, c->d_ray_stats, sizeof(h), hipMemcpyDeviceToHost));
+        s.rays_total = 0;
+        for (int d = 0; d < PRT_MAX_DEPTH; ++d) {
+            s.rays_per_depth[d] = h[d];
+            s.rays_total += h[d];
+        }
+        // slot 0 counted the dead (outside-the-image) lanes of partial tiles as well
+        s.rays_per_depth[0] -= std::min<uint64_t>(c->dead_paths, s.rays_per_depth[0]);
+        s.rays_total -= std::min<uint64_t>(c->dead_paths, s.rays_total);
+    }
+    *out = s;
+    return PRT_OK;
+}
+
+int prt_reset_stats(PrtContext* c) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = drain_events(c))) return rc;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->dead_paths = 0;
+    if (c->d_ray_stats) HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    return PRT_OK;
+}
+
+int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint32_t sample, PrtStats* out) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!out || max_depth == 0 || max_depth > PRT_MAX_DEPTH) return fail(c, PRT_ERR_INVALID, "bad arguments");
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
+    const bool timing = c->timing;
+    const uint64_t launches = c->stats.intersect_launches;
+    c->timing = false;
+    rc = run_batch(c, 1, max_depth, seed, sample, false, c->d_trav_stats);
+    c->timing = timing;
+    c->stats.intersect_launches = launches;
+    if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    unsigned long long t[4];
+    uint32_t cnt[PRT_MAX_DEPTH + 2];
+    HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    for (uint32_t d = 0; d < max_depth; ++d) {
+        out->rays_per_depth[d] = cnt[d];
+        out->rays_total += cnt[d];
+    }
+    const uint64_t dead = c->tm.n_pix_local - c->valid_local;
+    out->rays_per_depth[0] -= dead;
+    out->rays_total -= dead;
+    out->samples = 1;
+    out->bvh_node_visits = t[0];
+    out->bvh_tri_tests = t[1];
+    out->prim_tests = t[2];
+    return PRT_OK;
+}
+
+int prt_bvh_info(PrtContext* c, PrtBvhInfo* out) {
+    if (!c || !out) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    *out = c->bvh_info;
+    return PRT_OK;
+}
+
+int prt_bvh_read(PrtContext* c, float* nodes, float* tris) {
+    if (!c) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (nodes) memcpy(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4);
+    if (tris) memcpy(tris, c->tri_records.data(), c->tri_records.size() * 4);
+    return PRT_OK;
+}
+
+int prt_set_variant(PrtContext* c, int variant) {
+    if (!c) return PRT_ERR_INVALID;
+    c->variant = variant;
+    return PRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// prt_kernels.h — POD types shared by the HIP kernels (prt_kernels.hip) and the C-ABI host code
+// (prt_api.cpp), plus the launcher prototypes.  No kernel syntax here.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+#include "../../include/prt.h"
+
+struct f3 {
+    float x, y, z;
+};
+
+struct DevPrim {  // 28 dwords; mat/inv keep rows 0..2 of glm's column-major mat4 (cols 0..3)
+    uint32_t shape_type;
+    float p0, p1;
+    uint32_t material;
+    float mat[12];  // mat[c*3 + r]
+    float inv[12];
+};
+
+struct DevCamera {  // the Camera members GetCameraRay reads (reference: src/core/camera.h:134-141)
+    f3 pos, front, right, up;
+    float W, H, tan_fov_y;
+};
+
+struct DevScene {
+    const DevPrim* prims;
+    const float4* mat_rgbs;     // rgb + scalar
+    const uint32_t* mat_type;
+    const float4* nodes;        // 4 x float4 per BVH2 node (see bvh.h)
+    const float4* tris;         // 3 x float4 per triangle, leaf order: {P0, prim}, {P1, material}, {P2, 0}
+    const float4* tri_normals;  // 3 x float4 per triangle, leaf order
+    uint32_t n_prims;
+    uint32_t n_nodes;
+    uint32_t n_tris;
+    float pad;     // culling pad coefficient (2^-18): pad_ray = pad * (|o|_1 + extent)
+    float extent;  // max |coordinate| of any mesh vertex
+    float sky[3];
+};
+
+struct PrtTileMap {
+    uint32_t W, H, tiles_x, tiles_y, rank, world;
+    uint32_t n_tiles_local;  // tiles owned by this rank
+    uint32_t n_pix_local;    // n_tiles_local * 64
+    uint32_t stride;         // ceil(tiles_total / world) * 64: per-rank payload (float4 units), equal on all ranks
+};
+
+struct PrtRayBuf {
+    float4* o;  // origin.xyz, path id
+    float4* d;  // direction.xyz, rng state
+    float4* t;  // throughput.rgb, -
+};
+
+void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
+                       uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
+                       uint32_t max_depth);
+void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
+                          const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
+                          unsigned long long* stats);
+void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* hit,
+                      const PrtRayBuf& out, float4* rad, uint32_t* counts, uint32_t depth, uint32_t max_depth,
+                      uint32_t max_rays);
+void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
+                           const uint32_t* counts, uint32_t max_depth, unsigned long long* ray_stats);
+void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,
+                        uint32_t H, float* rgb, float* weight);
+void prt_launch_tonemap(hipStream_t st, const float* rgb, const float* weight, uint32_t n_pix, float exposure,
+                        float inv_gamma, uint8_t* out);
+void prt_launch_camera_rays(hipStream_t st, const DevCamera& cam, uint32_t n, const float* px, const float* py,
+                            float* o, float* d);
+void prt_launch_pack_rays(hipStream_t st, uint32_t n, const float* o, const float* d, const PrtRayBuf& out,
+                          uint32_t* counts);
+void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, const uint32_t* hit,
+                            PrtHit* out);
+void prt_launch_scatter_test(hipStream_t st, const DevScene& sc, uint32_t n, const float* in_d, const PrtHit* hits,
+                             uint32_t* rng_io, uint32_t* scattered, float* atten, float* emitted, float* o_out,
+                             float* d_out);

@@ -1,0 +1,526 @@
+// prt_kernels.hip — hand-written HIP kernels of the wavefront path tracer for gfx950 (MI355X).
+//
+// Pipeline per sample batch (one batch = `S` samples per local pixel in flight):
+//   k_raygen -> [ k_intersect -> k_shade ] x max_depth -> k_accumulate
+// replacing GenerateCameraRaysKernel / IntersectClosestKernel / ShadeHitsKernel / BlitRadianceKernel +
+// addBufferGPU of the reference (src/backend/cuda_wavefront/renderer.cu:186-348, src/core/film.cu:79-88).
+//
+// Layout decisions:
+//  * ray records are DENSE per bounce (structure of float4 arrays, slot k of bounce d), so every
+//    kernel reads coalesced 16-B/lane streams; the reference gathers per-pixel state through a queue of
+//    pixel indices instead (renderer.cu:226-228).
+//  * the hit buffer is one u32 per ray slot (primitive id); the shade kernel re-derives position/normal
+//    with the same device function the traversal used, so nothing else crosses HBM.
+//  * wave64 ballot compaction into the next bounce's buffer: one atomic per wave.
+#include "prt_kernels.h"
+
+#include "prt_device.h"
+
+#define HIT_MISS 0xFFFFFFFFu
+#define HIT_DEAD 0xFFFFFFFEu
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD's L2).  Give each XCD a
+// contiguous run of logical blocks so neighbouring rays (= neighbouring BVH subtrees) share an L2.
+// Bijective for every n.  Speed only; correctness never depends on placement.
+PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u;
+    const uint32_t xcd = b & 7u, i = b >> 3;
+    const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tile map: 8x8-pixel tiles, tile t (row-major) belongs to rank t % world.
+// ---------------------------------------------------------------------------------------------------------
+PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t& y) {
+    const uint32_t lt = pl >> 6, lane = pl & 63u;
+    const uint32_t gt = lt * tm.world + tm.rank;
+    const uint32_t tx = gt % tm.tiles_x, ty = gt / tm.tiles_x;
+    x = tx * 8u + (lane & 7u);
+    y = ty * 8u + (lane >> 3);
+    return gt < tm.tiles_x * tm.tiles_y && x < tm.W && y < tm.H;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ray generation (GenerateCameraRaysKernel, renderer.cu:186-204; pixel centres, cpu/renderer.cpp:45)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(DevCamera cam, PrtTileMap tm, uint32_t n_paths, uint32_t first_sample,
+                                                uint32_t seed, float4* __restrict__ ro, float4* __restrict__ rd,
+                                                float4* __restrict__ rt, float4* __restrict__ rad,
+                                                uint32_t* __restrict__ counts, uint32_t max_depth) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) {
+        counts[0] = n_paths;
+        for (uint32_t d = 1; d <= max_depth; ++d) counts[d] = 0;
+    }
+    if (i >= n_paths) return;
+    const uint32_t s_local = i / tm.n_pix_local;
+    const uint32_t pl = i - s_local * tm.n_pix_local;
+    uint32_t x, y;
+    if (!tile_pixel(tm, pl, x, y)) {
+        // outside the image: a dead path (keeps slot numbering dense and deterministic)
+        ro[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(i));
+        rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    f3 o, d;
+    camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
+    const uint32_t rng = path_seed(y * tm.W + x, first_sample + s_local, seed);
+    ro[i] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+    rd[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
+    rt[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Closest hit (IntersectClosestKernel, renderer.cu:206-272; semantics of PrimitiveList::Intersect,
+// src/core/primitive.cpp:21-59): linear scan over the analytic primitives + BVH2 traversal over all
+// mesh triangles.  The result equals the reference's linear scan over every primitive: the winner is the
+// smallest world distance^2, ties to the lowest primitive index, independent of visiting order.
+// ---------------------------------------------------------------------------------------------------------
+struct Closest {
+    float d2;
+    uint32_t id;    // hit id (analytic index, or n_prims + leaf slot)
+    uint32_t prim;  // global primitive index (tie-break key)
+};
+
+PRT_DEV void scan_analytic(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t& n_tests) {
+    for (uint32_t i = 0; i < sc.n_prims; ++i) {
+        WorldHit w;
+        analytic_hit(sc.prims[i], o, d, w);
+        ++n_tests;
+        if (w.has && w.d2 < best.d2) {  // strict <, first wins (primitive.cpp:44)
+            best.d2 = w.d2;
+            best.id = i;
+            best.prim = i;
+        }
+    }
+}
+
+PRT_DEV float limit_from_d2(float d2, float pad) {
+    // Upper bound on the local ray parameter of anything that could still win (d2' <= d2).
+    return (d2 < 3.0e38f) ? __builtin_sqrtf(d2) * 1.0000153f + 4.0f * pad : 3.4e38f;
+}
+
+template <int STACK, bool STATS>
+PRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
+                      uint32_t& n_tris) {
+    // Triangles carry the identity Transform: local origin = o, local direction = normalize(d)
+    // (TransformNormal, primitive.cpp:30).
+    const f3 ld = normalize3(d);
+    // Culling only (never changes a result): per-ray conservative padding of every box by `pad`.
+    const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+    const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+    const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+    const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+    // plane "min" is moved by -pad, plane "max" by +pad:  t_min = min*inv - (o+pad)*inv, t_max = max*inv - (o-pad)*inv
+    const float ax = (o.x + pad) * ix, ay = (o.y + pad) * iy, az = (o.z + pad) * iz;
+    const float bx = (o.x - pad) * ix, by = (o.y - pad) * iy, bz = (o.z - pad) * iz;
+    float tlimit = limit_from_d2(best.d2, pad);
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        if (node >= 0) {
+            const float4 q0 = sc.nodes[4 * (size_t)node + 0];
+            const float4 q1 = sc.nodes[4 * (size_t)node + 1];
+            const float4 q2 = sc.nodes[4 * (size_t)node + 2];
+            const float4 q3 = sc.nodes[4 * (size_t)node + 3];
+            if (STATS) ++n_nodes;
+            // left: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y); right: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
+            const float l0x = __builtin_fmaf(q0.x, ix, -ax), l1x = __builtin_fmaf(q0.w, ix, -bx);
+            const float l0y = __builtin_fmaf(q0.y, iy, -ay), l1y = __builtin_fmaf(q1.x, iy, -by);
+            const float l0z = __builtin_fmaf(q0.z, iz, -az), l1z = __builtin_fmaf(q1.y, iz, -bz);
+            const float r0x = __builtin_fmaf(q1.z, ix, -ax), r1x = __builtin_fmaf(q2.y, ix, -bx);
+            const float r0y = __builtin_fmaf(q1.w, iy, -ay), r1y = __builtin_fmaf(q2.z, iy, -by);
+            const float r0z = __builtin_fmaf(q2.x, iz, -az), r1z = __builtin_fmaf(q2.w, iz, -bz);
+            const float tnL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l0x, l1x), __builtin_fminf(l0y, l1y)),
+                                              __builtin_fmaxf(__builtin_fminf(l0z, l1z), 0.0f));
+            const float tfL = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l0x, l1x), __builtin_fmaxf(l0y, l1y)),
+                                              __builtin_fminf(__builtin_fmaxf(l0z, l1z), tlimit));
+            const float tnR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r0x, r1x), __builtin_fminf(r0y, r1y)),
+                                              __builtin_fmaxf(__builtin_fminf(r0z, r1z), 0.0f));
+            const float tfR = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r0x, r1x), __builtin_fmaxf(r0y, r1y)),
+                                              __builtin_fminf(__builtin_fmaxf(r0z, r1z), tlimit));
+            const bool hL = tnL <= tfL * 1.0000005f;
+            const bool hR = tnR <= tfR * 1.0000005f;
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            if (hL && hR) {
+                const bool lfirst = tnL <= tnR;
+                const int nearc = lfirst ? left : right;
+                const int farc = lfirst ? right : left;
+                if (sp < STACK) stk[sp * 256] = (uint32_t)farc;
+                ++sp;  // host guarantees STACK >= tree depth; the guard only prevents LDS corruption
+                node = nearc;
+                continue;
+            }
+            if (hL) {
+                node = left;
+                continue;
+            }
+            if (hR) {
+                node = right;
+                continue;
+            }
+        } else {
+            const uint32_t ref = ~(uint32_t)node;
+            const uint32_t first = ref >> 4, cnt = ref & 15u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t slot = first + t;
+                const float4 a = sc.tris[3 * (size_t)slot + 0];
+                const float4 b = sc.tris[3 * (size_t)slot + 1];
+                const float4 c = sc.tris[3 * (size_t)slot + 2];
+                if (STATS) ++n_tris;
+                f3 pos;
+                float b1, b2;
+                if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, ld, pos, b1, b2)) {
+                    const float d2 = dist2(o, pos);
+                    const uint32_t prim = __float_as_uint(a.w);
+                    if (d2 < best.d2 || (d2 == best.d2 && best.id != HIT_MISS && prim < best.prim)) {
+                        best.d2 = d2;
+                        best.id = sc.n_prims + slot;
+                        best.prim = prim;
+                        tlimit = limit_from_d2(d2, pad);
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = (sp < STACK) ? (int)stk[sp * 256] : -1;  // -1 == ~0 == empty leaf
+    }
+}
+
+template <int STACK, bool STATS>
+__global__ void __launch_bounds__(256) k_intersect(DevScene sc, const float4* __restrict__ ro,
+                                                   const float4* __restrict__ rd, uint32_t* __restrict__ hit,
+                                                   const uint32_t* __restrict__ count_ptr,
+                                                   unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t s_stack[STACK * 256];
+    const uint32_t count = *count_ptr;
+    const uint32_t nb_live = (count + 255u) >> 8;
+    if (blockIdx.x >= nb_live) return;
+    const uint32_t k = xcd_remap(blockIdx.x, nb_live) * 256u + threadIdx.x;
+    uint32_t n_nodes = 0, n_tris = 0, n_ptests = 0;
+    if (k < count) {
+        const float4 O = ro[k];
+        const float4 D = rd[k];
+        if (D.x == 0.0f && D.y == 0.0f && D.z == 0.0f) {
+            hit[k] = HIT_DEAD;
+        } else {
+            const f3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
+            Closest best;
+            best.d2 = 3.402823466e+38f;  // FLT_MAX (primitive.cpp:23)
+            best.id = HIT_MISS;
+            best.prim = 0xFFFFFFFFu;
+            scan_analytic(sc, o, d, best, n_ptests);
+            if (sc.n_nodes) traverse<STACK, STATS>(sc, o, d, best, &s_stack[threadIdx.x], n_nodes, n_tris);
+            hit[k] = best.id;
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        atomicAdd(&stats[2], (unsigned long long)n_ptests);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shade + scatter + compaction (ShadeHitsKernel, renderer.cu:274-335; the miss branch of
+// IntersectClosestKernel, renderer.cu:263-271; path logic of TraceRayGPU, cuda_megakernel/renderer.cu:81-119).
+// Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
+// material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_shade(DevScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                               const float4* __restrict__ rt, const uint32_t* __restrict__ hit,
+                                               float4* __restrict__ no, float4* __restrict__ nd,
+                                               float4* __restrict__ nt, float4* __restrict__ rad,
+                                               uint32_t* __restrict__ counts, uint32_t depth, uint32_t max_depth) {
+    const uint32_t count = counts[depth];
+    const uint32_t wave_base = (blockIdx.x * 256u + threadIdx.x) & ~63u;
+    if (wave_base >= count) return;  // whole wave exits together
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    bool want = false;
+    float4 O2, D2, T2;
+    if (k < count) {
+        const float4 O = ro[k];
+        const float4 D = rd[k];
+        const float4 T = rt[k];
+        const uint32_t id = hit[k];
+        const uint32_t pid = __float_as_uint(O.w);
+        uint32_t rng = __float_as_uint(D.w);
+        const f3 thr = mk3(T.x, T.y, T.z);
+        if (id == HIT_DEAD) {
+            // nothing: k_raygen already zeroed rad[pid]
+        } else if (id == HIT_MISS) {
+            const f3 L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);
+            rad[pid] = make_float4(L.x, L.y, L.z, 0.f);
+        } else {
+            const f3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
+            WorldHit w;
+            world_hit_from_id(sc, id, o, d, w);
+            const uint32_t type = sc.mat_type[w.material];
+            const float4 rgbs = sc.mat_rgbs[w.material];
+            f3 atten, emitted, so, sd;
+            bool scattered = false;
+            if (depth + 1u >= max_depth) {
+                emitted = (type == 4u) ? mk3(rgbs.x, rgbs.y, rgbs.z) : mk3(0.f, 0.f, 0.f);
+            } else {
+                scattered = material_scatter(type, rgbs, d, w.pos, w.normal, w.front, rng, atten, emitted, so, sd);
+            }
+            if (!scattered) {
+                const f3 L = thr * emitted;
+                rad[pid] = make_float4(L.x, L.y, L.z, 0.f);
+            } else {
+                const f3 t2 = thr * atten;
+                const f3 d2 = normalize3(sd);  // scatteredRay.Normalize(), cpu/renderer.cpp:84
+                O2 = make_float4(so.x, so.y, so.z, O.w);
+                D2 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(rng));
+                T2 = make_float4(t2.x, t2.y, t2.z, 0.f);
+                want = true;
+            }
+        }
+    }
+    const uint32_t slot = wave_alloc(&counts[depth + 1u], want);
+    if (want) {
+        no[slot] = O2;
+        nd[slot] = D2;
+        nt[slot] = T2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Film accumulate (Film::AddSample, src/core/film.cu:37-55; BlitRadianceKernel + addBufferGPU,
+// renderer.cu:337-348, film.cu:79-88): samples are added in sample order, weight 1 each.
+// film_local is tile-ordered [n_pix_local] float4 {r_sum, g_sum, b_sum, weight}.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ rad, float4* __restrict__ film_local,
+                                                    PrtTileMap tm, uint32_t S, const uint32_t* __restrict__ counts,
+                                                    uint32_t max_depth, unsigned long long* __restrict__ ray_stats) {
+    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+    if (pl == 0) {
+        for (uint32_t d = 0; d < max_depth; ++d) ray_stats[d] += counts[d];
+    }
+    if (pl >= tm.n_pix_local) return;
+    uint32_t x, y;
+    if (!tile_pixel(tm, pl, x, y)) return;
+    float4 f = film_local[pl];
+    const float weight = 1.0f;
+    for (uint32_t s = 0; s < S; ++s) {
+        const float4 r = rad[(size_t)s * tm.n_pix_local + pl];
+        f.x += r.x * weight;
+        f.y += r.y * weight;
+        f.z += r.z * weight;
+        f.w += weight;
+    }
+    film_local[pl] = f;
+}
+
+// Un-tile `world` gathered rank payloads (each `stride` float4) into the Film layout
+// (m_Accum[3*(y*W+x)+c], m_Weights[y*W+x]; src/core/film.h:54-60).
+__global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ gathered, uint32_t world, uint32_t stride,
+                                                 uint32_t W, uint32_t H, float* __restrict__ rgb,
+                                                 float* __restrict__ weight) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= W * H) return;
+    const uint32_t x = idx % W, y = idx / W;
+    const uint32_t tiles_x = (W + 7u) >> 3;
+    const uint32_t gt = (y >> 3) * tiles_x + (x >> 3);
+    const uint32_t rank = gt % world, lt = gt / world;
+    const uint32_t pl = lt * 64u + (y & 7u) * 8u + (x & 7u);
+    const float4 f = gathered[(size_t)rank * stride + pl];
+    rgb[3 * (size_t)idx + 0] = f.x;
+    rgb[3 * (size_t)idx + 1] = f.y;
+    rgb[3 * (size_t)idx + 2] = f.z;
+    weight[idx] = f.w;
+}
+
+// Film::UpdateDisplayGPU (updateDisplayKernel, src/core/film.cu:101-121) with the bounds check the
+// reference lacks; one thread per channel.
+__global__ void __launch_bounds__(256) k_tonemap(const float* __restrict__ rgb, const float* __restrict__ weight,
+                                                 uint32_t n_pix, float exposure, float inv_gamma,
+                                                 uint8_t* __restrict__ out) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_pix * 4u) return;
+    const uint32_t p = idx >> 2, c = idx & 3u;
+    if (c == 3u) {
+        out[idx] = 255;
+        return;
+    }
+    const float w = weight[p];
+    float value = 0.0f;
+    if (w > 0.0f) {
+        const float invW = 1.0f / w;
+        value = rgb[3 * (size_t)p + c] * invW;
+        value = value * exposure;
+        value = value / (1.0f + value);
+        value = powf(value, inv_gamma);
+    }
+    value = __builtin_fmaxf(0.0f, __builtin_fminf(1.0f, value));
+    out[idx] = (uint8_t)(value * 255.0f + 0.5f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Function-level kernels behind prt_camera_rays / prt_closest_hit / prt_scatter (parity tests).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_camera_rays(DevCamera cam, uint32_t n, const float* __restrict__ px, const float* __restrict__ py,
+                              float* __restrict__ o_out, float* __restrict__ d_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    f3 o, d;
+    camera_ray(cam, px[i], py[i], o, d);
+    o_out[3 * i + 0] = o.x;
+    o_out[3 * i + 1] = o.y;
+    o_out[3 * i + 2] = o.z;
+    d_out[3 * i + 0] = d.x;
+    d_out[3 * i + 1] = d.y;
+    d_out[3 * i + 2] = d.z;
+}
+
+__global__ void k_pack_rays(uint32_t n, const float* __restrict__ o, const float* __restrict__ d,
+                            float4* __restrict__ ro, float4* __restrict__ rd, uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) counts[0] = n;
+    if (i >= n) return;
+    ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], __uint_as_float(i));
+    rd[i] = make_float4(d[3 * i], d[3 * i + 1], d[3 * i + 2], 0.f);
+}
+
+__global__ void k_hit_records(DevScene sc, uint32_t n, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                              const uint32_t* __restrict__ hit, PrtHit* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    PrtHit h;
+    h.prim = -1;
+    h.front_face = 0;
+    h.material_id = 0xFFFFFFFFu;
+    h.d2 = 3.402823466e+38f;
+    h.position[0] = h.position[1] = h.position[2] = 0.f;
+    h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
+    const uint32_t id = hit[i];
+    if (id != HIT_MISS && id != HIT_DEAD) {
+        const float4 O = ro[i], D = rd[i];
+        WorldHit w;
+        world_hit_from_id(sc, id, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), w);
+        if (w.has) {
+            h.prim = w.prim;
+            h.front_face = w.front ? 1u : 0u;
+            h.material_id = w.material;
+            h.d2 = w.d2;
+            h.position[0] = w.pos.x;
+            h.position[1] = w.pos.y;
+            h.position[2] = w.pos.z;
+            h.normal[0] = w.normal.x;
+            h.normal[1] = w.normal.y;
+            h.normal[2] = w.normal.z;
+        }
+    }
+    out[i] = h;
+}
+
+__global__ void k_scatter_test(DevScene sc, uint32_t n, const float* __restrict__ in_d, const PrtHit* __restrict__ hits,
+                               uint32_t* __restrict__ rng_io, uint32_t* __restrict__ scattered,
+                               float* __restrict__ atten_o, float* __restrict__ emit_o, float* __restrict__ o_out,
+                               float* __restrict__ d_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const PrtHit h = hits[i];
+    uint32_t rng = rng_io[i];
+    f3 atten, emitted, so, sd;
+    const uint32_t m = h.material_id;
+    const bool sc_ = material_scatter(sc.mat_type[m], sc.mat_rgbs[m], mk3(in_d[3 * i], in_d[3 * i + 1], in_d[3 * i + 2]),
+                                      mk3(h.position[0], h.position[1], h.position[2]),
+                                      mk3(h.normal[0], h.normal[1], h.normal[2]), h.front_face != 0u, rng, atten,
+                                      emitted, so, sd);
+    rng_io[i] = rng;
+    scattered[i] = sc_ ? 1u : 0u;
+    atten_o[3 * i + 0] = atten.x;
+    atten_o[3 * i + 1] = atten.y;
+    atten_o[3 * i + 2] = atten.z;
+    emit_o[3 * i + 0] = emitted.x;
+    emit_o[3 * i + 1] = emitted.y;
+    emit_o[3 * i + 2] = emitted.z;
+    o_out[3 * i + 0] = so.x;
+    o_out[3 * i + 1] = so.y;
+    o_out[3 * i + 2] = so.z;
+    d_out[3 * i + 0] = sd.x;
+    d_out[3 * i + 1] = sd.y;
+    d_out[3 * i + 2] = sd.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host launchers (plain functions; prt_api.cpp has no kernel syntax).
+// ---------------------------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
+
+void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
+                       uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
+                       uint32_t max_depth) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_paths)), dim3(256), 0, st, cam, tm, n_paths, first_sample, seed,
+                       out.o, out.d, out.t, rad, counts, max_depth);
+}
+
+void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
+                          const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
+                          unsigned long long* stats) {
+    const dim3 grid(blocks_for(max_rays)), block(256);
+    (void)variant;
+    if (stats) {
+        if (stack_depth <= 32)
+            hipLaunchKernelGGL((k_intersect<32, true>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+        else
+            hipLaunchKernelGGL((k_intersect<64, true>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+    } else {
+        if (stack_depth <= 32)
+            hipLaunchKernelGGL((k_intersect<32, false>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+        else
+            hipLaunchKernelGGL((k_intersect<64, false>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+    }
+}
+
+void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* hit,
+                      const PrtRayBuf& out, float4* rad, uint32_t* counts, uint32_t depth, uint32_t max_depth,
+                      uint32_t max_rays) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_rays)), dim3(256), 0, st, sc, in.o, in.d, in.t, hit, out.o, out.d,
+                       out.t, rad, counts, depth, max_depth);
+}
+
+void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
+                           const uint32_t* counts, uint32_t max_depth, unsigned long long* ray_stats) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(tm.n_pix_local ? tm.n_pix_local : 1)), dim3(256), 0, st, rad,
+                       film_local, tm, S, counts, max_depth, ray_stats);
+}
+
+void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,
+                        uint32_t H, float* rgb, float* weight) {
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for((uint64_t)W * H)), dim3(256), 0, st, gathered, world, stride, W, H,
+                       rgb, weight);
+}
+
+void prt_launch_tonemap(hipStream_t st, const float* rgb, const float* weight, uint32_t n_pix, float exposure,
+                        float inv_gamma, uint8_t* out) {
+    hipLaunchKernelGGL(k_tonemap, dim3(blocks_for((uint64_t)n_pix * 4u)), dim3(256), 0, st, rgb, weight, n_pix,
+                       exposure, inv_gamma, out);
+}
+
+void prt_launch_camera_rays(hipStream_t st, const DevCamera& cam, uint32_t n, const float* px, const float* py,
+                            float* o, float* d) {
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocks_for(n)), dim3(256), 0, st, cam, n, px, py, o, d);
+}
+
+void prt_launch_pack_rays(hipStream_t st, uint32_t n, const float* o, const float* d, const PrtRayBuf& out,
+                          uint32_t* counts) {
+    hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n)), dim3(256), 0, st, n, o, d, out.o, out.d, counts);
+}
+
+void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, const uint32_t* hit,
+                            PrtHit* out) {
+    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(n)), dim3(256), 0, st, sc, n, in.o, in.d, hit, out);
+}
+
+void prt_launch_scatter_test(hipStream_t st, const DevScene& sc, uint32_t n, const float* in_d, const PrtHit* hits,
+                             uint32_t* rng_io, uint32_t* scattered, float* atten, float* emitted, float* o_out,
+                             float* d_out) {
+    hipLaunchKernelGGL(k_scatter_test, dim3(blocks_for(n)), dim3(256), 0, st, sc, n, in_d, hits, rng_io, scattered,
+                       atten, emitted, o_out, d_out);
+}

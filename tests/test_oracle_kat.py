@@ -1,0 +1,343 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no tests, golden vectors or fixtures and cannot be compiled here (PARITY UNPINNED, see
+oracle/prt_oracle.h), so the oracle is pinned by hand-derived answers of the reference's formulas
+(each case cites the reference lines it exercises) and by its own internal invariants.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import util
+from util import orc, prt
+
+SQ2 = math.sqrt(2.0)
+
+
+# ---- RNG contract -------------------------------------------------------------------------------------------
+def py_pcg(v):
+    state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+def test_pcg_hash_matches_definition():
+    # optix/device_types.h:109-114 restated independently in Python integers
+    for v in [0, 1, 2, 0xFFFFFFFF, 0x12345678, 719393, 65535]:
+        assert orc.pcg_hash(v) == py_pcg(v)
+
+
+def test_path_seed_is_optix_seeding_when_seed_zero():
+    # optix/device_programs.cu:169: pcg_hash(pixelIndex ^ (frameIndex * 719393u))
+    for pixel, frame in [(0, 0), (17, 3), (2073599, 255)]:
+        assert orc.path_seed(pixel, frame, 0) == py_pcg(pixel ^ ((frame * 719393) & 0xFFFFFFFF))
+    assert orc.path_seed(5, 1, 9) != orc.path_seed(5, 1, 0)
+
+
+def test_random_is_top24_bits_in_unit_interval():
+    u, st = orc.random_floats(123, 1000)
+    assert (u >= 0).all() and (u < 1).all()
+    s = 123
+    for k in range(5):
+        s = py_pcg(s)
+        assert u[k] == np.float32((s >> 8) * 2.0 ** -24)
+    assert 0.45 < u.mean() < 0.55
+
+
+def test_random_unit_vector_is_unit_and_consumes_multiples_of_three():
+    # math.h:26-36
+    for seed in range(20):
+        v, st = orc.random_unit_vector(seed)
+        assert abs(float(np.linalg.norm(v.astype(np.float64))) - 1.0) < 1e-6
+        # replay: find k with 3k draws
+        s, k = seed, 0
+        while True:
+            xs = []
+            for _ in range(3):
+                s = py_pcg(s)
+                xs.append(np.float32(-1.0) + np.float32(2.0) * np.float32((s >> 8) * 2.0 ** -24))
+            k += 1
+            l2 = np.float32(np.float32(xs[0] * xs[0] + xs[1] * xs[1]) + xs[2] * xs[2])
+            if 1e-8 < l2 <= 1.0:
+                break
+        assert st == s
+
+
+# ---- camera (camera.h:10-16, 103-132) ---------------------------------------------------------------------------
+def test_camera_basis_axis_aligned():
+    cam = prt.Camera(position=(0, 0, 5), front=(0, 0, -2), width=100, height=50).desc()
+    f, r, u = orc.camera_basis(cam)
+    assert np.allclose(f, [0, 0, -1]) and np.allclose(r, [1, 0, 0]) and np.allclose(u, [0, 1, 0])
+
+
+def test_camera_center_and_corner_rays():
+    cam = prt.Camera(position=(0, 0, 5), front=(0, 0, -1), width=100, height=50).desc()
+    o, d = orc.camera_rays(cam, [50.0, 100.0, 0.0], [25.0, 0.0, 50.0])
+    assert np.array_equal(o, np.tile(np.float32([0, 0, 5]), (3, 1)))
+    assert np.allclose(d[0], [0, 0, -1], atol=1e-7)
+    t = math.tan(0.5)
+    c = np.array([2 * t, t, -1.0])
+    assert np.allclose(d[1], c / np.linalg.norm(c), atol=1e-6)  # top-right corner: +x, +y (row 0 = top)
+    c2 = np.array([-2 * t, -t, -1.0])
+    assert np.allclose(d[2], c2 / np.linalg.norm(c2), atol=1e-6)
+
+
+def test_tanf_half_equals_rounded_double_tan():
+    # camera.h:111 is `tan(0.5f)`: float or double overload depending on the compiler; both round to the same fp32
+    assert np.float32(math.tan(0.5)) == np.tan(np.float32(0.5))
+
+
+# ---- shapes ----------------------------------------------------------------------------------------------------
+def test_circle_front_hit():
+    # shape.h:157-203: origin (0,0,5), dir -z, r=1 -> roots 4 and 6, nearer=4, front face, normal +z
+    has, pos, n, front = orc.shape_intersect(0, [1.0], [0, 0, 5], [0, 0, -1])
+    assert has and front and np.allclose(pos, [0, 0, 1]) and np.allclose(n, [0, 0, 1])
+
+
+def test_circle_inside_is_back_face_with_flipped_normal():
+    has, pos, n, front = orc.shape_intersect(0, [2.0], [0, 0, 0], [1, 0, 0])
+    assert has and not front and np.allclose(pos, [2, 0, 0]) and np.allclose(n, [-1, 0, 0])
+
+
+def test_circle_miss_and_behind():
+    assert not orc.shape_intersect(0, [1.0], [0, 3, 5], [0, 0, -1])[0]  # disc < 0
+    assert not orc.shape_intersect(0, [1.0], [0, 0, 5], [0, 0, 1])[0]  # both roots < tMin
+
+
+def test_circle_tmin_boundary():
+    # origin just outside the surface moving outward: roots -2.0005 and -0.0005 -> no hit;
+    # origin 0.0005 inside moving outward: far root 0.0005 < tMin=1e-3 -> no hit (shape.h:128,173-192)
+    assert not orc.shape_intersect(0, [1.0], [0, 0, 1.0005], [0, 0, 1])[0]
+    assert not orc.shape_intersect(0, [1.0], [0, 0, 0.9995], [0, 0, 1])[0]
+    has, pos, n, front = orc.shape_intersect(0, [1.0], [0, 0, 0.99], [0, 0, 1])
+    assert has and not front and np.allclose(pos, [0, 0, 1], atol=1e-6)
+
+
+def test_quad_hit_front_back_and_strict_edges():
+    # shape.h:213-239
+    has, pos, n, front = orc.shape_intersect(1, [2.0, 4.0], [0.5, 3, 1.5], [0, -1, 0])
+    assert has and front and np.allclose(pos, [0.5, 0, 1.5]) and np.array_equal(n, np.float32([0, 1, 0]))
+    has, pos, n, front = orc.shape_intersect(1, [2.0, 4.0], [0.5, -3, 1.5], [0, 1, 0])
+    assert has and not front and np.array_equal(n, np.float32([0, -1, 0]))
+    assert not orc.shape_intersect(1, [2.0, 4.0], [1.0, 3, 0], [0, -1, 0])[0]  # p.x^2 < (w/2)^2 is strict
+    assert not orc.shape_intersect(1, [2.0, 4.0], [0, 3, 2.0], [0, -1, 0])[0]
+    assert not orc.shape_intersect(1, [2.0, 4.0], [0, 3, 0], [1, 0, 0])[0]  # |d.y| < 1e-8
+    assert not orc.shape_intersect(1, [2.0, 4.0], [0, 0.0005, 0], [0, -1, 0])[0]  # t <= tMin
+
+
+TRI = [0, 0, 0, 1, 0, 0, 0, 1, 0] + [0, 0, 1] * 3
+
+
+def test_triangle_hit_barycentric_position_and_two_sidedness():
+    # shape.h:262-303
+    has, pos, n, front = orc.shape_intersect(2, TRI, [0.25, 0.25, 2], [0, 0, -1])
+    assert has and front and np.allclose(pos, [0.25, 0.25, 0]) and np.allclose(n, [0, 0, 1])
+    has, pos, n, front = orc.shape_intersect(2, TRI, [0.25, 0.25, -2], [0, 0, 1])
+    assert has and not front and np.allclose(n, [0, 0, -1])
+
+
+def test_triangle_rejects():
+    assert not orc.shape_intersect(2, TRI, [0.8, 0.8, 2], [0, 0, -1])[0]  # b1 + b2 > 1
+    assert not orc.shape_intersect(2, TRI, [-0.1, 0.2, 2], [0, 0, -1])[0]  # b1 < 0
+    assert not orc.shape_intersect(2, TRI, [0.2, 0.2, 2], [1, 0, 0])[0]  # divisor == 0 (parallel)
+    assert not orc.shape_intersect(2, TRI, [0.2, 0.2, 0.0005], [0, 0, -1])[0]  # t < tMin
+    assert orc.shape_intersect(2, TRI, [0.0, 0.0, 1], [0, 0, -1])[0]  # vertex: b1 = b2 = 0 accepted
+
+
+def test_triangle_normal_is_interpolated_unnormalised():
+    tri = [0, 0, 0, 1, 0, 0, 0, 1, 0] + [0, 0, 1, 0, 0, 2, 0, 0, 4]
+    has, pos, n, front = orc.shape_intersect(2, tri, [0.5, 0.25, 2], [0, 0, -1])
+    assert has and np.allclose(n, [0, 0, 0.25 * 1 + 0.5 * 2 + 0.25 * 4])
+
+
+def test_aabb_intersect_p():
+    # geometry.h:170-192
+    assert orc.aabb_intersect_p([-1, -1, -1], [1, 1, 1], [0, 0, 5], [0, 0, -1])
+    assert not orc.aabb_intersect_p([-1, -1, -1], [1, 1, 1], [0, 0, 5], [0, 0, 1])
+    assert not orc.aabb_intersect_p([-1, -1, -1], [1, 1, 1], [3, 0, 5], [0, 0, -1])
+    assert orc.aabb_intersect_p([-1, -1, -1], [1, 1, 1], [0, 0, 0], [1, 1, 1])
+
+
+# ---- transforms (geometry.h:139-148, scene.cpp:9-17) ----------------------------------------------------------
+def test_make_transform_translate_scale():
+    mat, inv = orc.make_transform((2, 2, 2), (0, 0, 0), (5, 6, 0))
+    M = mat.reshape(4, 4).T  # column-major -> math layout
+    assert np.allclose(M, [[2, 0, 0, 5], [0, 2, 0, 6], [0, 0, 2, 0], [0, 0, 0, 1]])
+    assert np.allclose(inv.reshape(4, 4).T @ M, np.eye(4), atol=1e-6)
+
+
+def test_make_transform_rotate_x_90_maps_y_to_z():
+    # eulerAngleXYZ with only X: the standard right-handed Rx (columns (0,c,s), (0,-s,c))
+    mat, inv = orc.make_transform((1, 1, 1), (90, 0, 0), (0, 9, 0))
+    p = orc.transform_point(mat, [0, 1, 0])
+    assert np.allclose(p, [0, 9, 1], atol=1e-6)
+    p = orc.transform_point(mat, [0, 0, 1])
+    assert np.allclose(p, [0, 8, 0], atol=1e-6)
+
+
+def test_transform_normal_uses_transpose_and_normalises():
+    mat, inv = orc.make_transform((1, 1, 1), (90, 0, 0), (0, 0, 0))
+    # TransformNormal(inv, n) = normalize(inv^T n) = R n for a rotation
+    n = orc.transform_normal(inv, [0, 1, 0])
+    assert np.allclose(n, [0, 0, 1], atol=1e-6)
+    # the quirk of primitive.cpp:30: directions go to local space with TransformNormal(Mat, d) = R^T d
+    d = orc.transform_normal(mat, [0, 0, 1])
+    assert np.allclose(d, [0, 1, 0], atol=1e-6)
+    mat2, inv2 = orc.make_transform((2, 2, 2), (0, 0, 0), (0, 0, 0))
+    assert np.allclose(orc.transform_normal(mat2, [0, 0, 3]), [0, 0, 1])
+
+
+# ---- presets (scene.cpp:62-350) -----------------------------------------------------------------------------------
+def test_preset_counts():
+    want = {"DEFAULT": (8, 8), "LIGHT_TEST": (12, 12), "MATERIAL_TEST": (4, 4), "CORNELL": (4, 4),
+            "RANDOM_BALLS_SMALL": (109, 109), "RANDOM_BALLS_MEDIUM": (409, 409), "RANDOM_BALLS_LARGE": (809, 809)}
+    for name, (nm, npr) in want.items():
+        mats, prims = orc.scene_preset(prt.capi.PRESET_NAMES[name])
+        assert (len(mats), len(prims)) == (nm, npr), name
+
+
+def test_preset_cornell_layout():
+    mats, prims = orc.scene_preset(prt.capi.PRESET_CORNELL)
+    assert [m.type for m in mats] == [1, 1, 1, 4]
+    assert [p.material_id for p in prims] == [2, 0, 1, 3]  # white, red, green, light
+    assert all(p.shape_type == 1 and p.shape_param[0] == 10 and p.shape_param[1] == 10 for p in prims)
+    # the three rotated quads lie in planes z = const (SURVEY header fact 3): local normal (0,1,0) -> (0,0,1)
+    for p in prims[1:]:
+        n = orc.transform_normal(np.array(p.inv[:], np.float32), [0, 1, 0])
+        assert np.allclose(n, [0, 0, 1], atol=1e-6)
+
+
+def test_preset_random_balls_is_deterministic_and_in_range():
+    mats, prims = orc.scene_preset(prt.capi.PRESET_RANDOM_BALLS_SMALL)
+    mats2, prims2 = orc.scene_preset(prt.capi.PRESET_RANDOM_BALLS_SMALL)
+    assert bytes(prims) == bytes(prims2) and bytes(mats) == bytes(mats2)
+    assert prims[0].shape_type == 1 and prims[0].shape_param[0] == 200
+    for p in prims[1:101]:
+        r = p.shape_param[0]
+        assert 0.2 <= r <= 1.0 and p.mat[13] == r and -40 <= p.mat[12] <= 40 and -40 <= p.mat[14] <= 40
+    assert all(mats[p.material_id].type == 4 and p.shape_param[0] == 1.5 and p.mat[13] == 8.0 for p in prims[101:])
+    kinds = [mats[p.material_id].type for p in prims[1:101]]
+    assert kinds.count(1) > kinds.count(2) > kinds.count(3) > 0
+
+
+# ---- materials (material.h) -------------------------------------------------------------------------------------------
+def _hit(pos=(0, 0, 0), normal=(0, 1, 0), front=1, mat=0):
+    h = np.zeros(1, dtype=prt.capi.HIT_DTYPE)
+    h["prim"] = 0
+    h["front_face"] = front
+    h["material_id"] = mat
+    h["position"] = pos
+    h["normal"] = normal
+    return h[0]
+
+
+def _mat(t, rgb=(0, 0, 0), s=0.0):
+    m = prt.capi.PrtMaterial()
+    m.type = t
+    m.rgb[:] = rgb
+    m.scalar = s
+    return m
+
+
+def test_lambertian_scatter():
+    # material.h:16-31: dir = normalize(n + RandomUnitVector), attenuation = albedo, always scatters
+    sc, att, em, oo, od, st = orc.scatter(_mat(1, (0.2, 0.4, 0.6)), (0, -1, 0), _hit(pos=(1, 2, 3)), 42)
+    ruv, st2 = orc.random_unit_vector(42)
+    want = np.float32([0, 1, 0]) + ruv
+    want = want / np.linalg.norm(want.astype(np.float64))
+    assert sc and st == st2 and np.allclose(od, want, atol=1e-6)
+    assert np.array_equal(att, np.float32([0.2, 0.4, 0.6])) and np.array_equal(oo, np.float32([1, 2, 3]))
+    assert not em.any()
+
+
+def test_metal_mirror_reflection_and_rng_draw_at_zero_roughness():
+    # material.h:48-57: RandomUnitVector is drawn even when roughness == 0
+    d = np.float32([1, -1, 0]) / np.float32(SQ2)
+    sc, att, em, oo, od, st = orc.scatter(_mat(2, (0.9, 0.9, 0.9), 0.0), d, _hit(), 7)
+    assert sc and np.allclose(od, [1 / SQ2, 1 / SQ2, 0], atol=1e-6)
+    assert st == orc.random_unit_vector(7)[1] and st != 7
+
+
+def test_metal_absorbs_when_scattered_below_surface():
+    # returns dot(out, n) > 0: a grazing ray with large roughness can go below
+    d = np.float32([1, -1e-3, 0])
+    d = d / np.linalg.norm(d)
+    results = [orc.scatter(_mat(2, (1, 1, 1), 1.0), d, _hit(), s)[0] for s in range(200)]
+    assert any(results) and not all(results)
+
+
+def test_dielectric_normal_incidence_refracts_straight_or_reflects_back():
+    # material.h:76-95 at cos=1: schlick = r0 = ((1-ri)/(1+ri))^2 with ri = 1/1.5 -> 0.04
+    outs = []
+    for s in range(300):
+        sc, att, em, oo, od, st = orc.scatter(_mat(3, s=1.5), (0, -1, 0), _hit(), s)
+        assert sc and np.array_equal(att, np.float32([1, 1, 1]))
+        u, _ = orc.random_floats(s, 1)
+        if 0.04 > u[0] + 1e-6:
+            assert np.allclose(od, [0, 1, 0], atol=1e-6)
+        elif 0.04 < u[0] - 1e-6:
+            assert np.allclose(od, [0, -1, 0], atol=1e-6)
+        outs.append(od[1] > 0)
+    assert 0 < sum(outs) < 40  # ~4 % reflect
+
+
+def test_dielectric_total_internal_reflection_draws_no_rng():
+    # back face, ri = 1.5, 60 deg: ri*sin > 1 -> reflect; Random() is NOT drawn (short-circuit, material.h:88)
+    d = np.float32([math.sin(math.radians(60)), math.cos(math.radians(60)), 0])  # travelling +y inside, n = (0,-1,0)
+    sc, att, em, oo, od, st = orc.scatter(_mat(3, s=1.5), d, _hit(normal=(0, -1, 0), front=0), 99)
+    assert sc and st == 99 and np.allclose(od, [d[0], -d[1], 0], atol=1e-6)
+
+
+def test_dielectric_refraction_obeys_snell():
+    th = math.radians(30)
+    d = np.float32([math.sin(th), -math.cos(th), 0])
+    for s in range(50):
+        sc, att, em, oo, od, st = orc.scatter(_mat(3, s=1.5), d, _hit(), s)
+        if od[1] < 0:
+            assert abs(od[0] - math.sin(th) / 1.5) < 1e-6  # out dir is not normalised here but |out| = 1 for unit input
+            break
+    else:
+        pytest.fail("never refracted")
+
+
+def test_emissive_emits_and_never_scatters():
+    sc, att, em, oo, od, st = orc.scatter(_mat(4, (10, 5, 5)), (0, -1, 0), _hit(), 3)
+    assert not sc and np.array_equal(em, np.float32([10, 5, 5])) and st == 3
+
+
+# ---- closest hit / path / film ----------------------------------------------------------------------------------------
+def test_closest_hit_picks_nearest_and_first_on_ties():
+    # primitive.cpp:42-48: strict <, so of two coincident quads the first in the list wins
+    sc = prt.Scene(preset=None)
+    a = sc.AddLambertian((1, 0, 0))
+    b = sc.AddLambertian((0, 1, 0))
+    sc.AddQuad(2, 2, a)
+    sc.AddQuad(2, 2, b)
+    sc.AddQuad(2, 2, b, translation=(0, 1, 0))
+    h = util.oracle_scene(sc).closest_hit([[0, 5, 0], [0, 0.5, 0], [5, 5, 5]], [[0, -1, 0], [0, -1, 0], [0, 1, 0]])
+    assert h["prim"].tolist() == [2, 0, -1]
+    assert h["material_id"][1] == a and h["d2"][1] == np.float32(0.25) and h["front_face"][0] == 1
+
+
+def test_trace_cornell_light_and_sky():
+    sc = prt.Scene("CORNELL")
+    osc = util.oracle_scene(sc)
+    # straight down onto the white floor: Lambertian bounce; depth 1 -> no emission seen -> 0
+    L, segs, _ = osc.trace([0, 3, 1], [0, -1, 0], 1, 5)
+    assert segs == 1 and not L.any()
+    # towards the light quad at (0,9,0) (plane z = 0): hits emissive -> L = 15, path ends
+    L, segs, _ = osc.trace([0, 9, 4], [0, 0, -1], 20, 5)
+    assert segs == 1 and np.array_equal(L, np.float32([15, 15, 15]))
+    # miss -> sky (cpu/renderer.h:31)
+    L, segs, _ = osc.trace([0, 3, 4], [0, 0, 1], 20, 5)
+    assert segs == 1 and np.array_equal(L, np.float32([0.4, 0.3, 0.6]))
+
+
+def test_tonemap_known_values():
+    # film.cu:134-194: mean -> x/(1+x) -> pow(1/2.2) -> uint8(v*255+0.5); weight 0 -> black; alpha 255
+    acc = np.float32([[2, 0, 1e9], [5, 5, 5]])
+    w = np.float32([2, 0])
+    out = orc.tonemap(acc, w)
+    assert out[0].tolist() == [int((0.5 ** (1 / 2.2)) * 255 + 0.5), 0, 255, 255]
+    assert out[1].tolist() == [0, 0, 0, 255]
