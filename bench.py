@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s of the wavefront path tracer on BASELINE.json's metric config.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): C3 of SURVEY.md §8(d) — the bundled dragon.ply refined by deterministic
+longest-edge bisection to 870,000 triangles, on a ground quad under an emissive quad, 1920x1080,
+max_depth = 5 segments ("4 bounces"), synthetic (there is no 1M-triangle scene in the reference).
+A "step" is one progressive pass of --spp-per-step samples per pixel over the whole frame, followed by the
+per-frame gather of the ranks' tiles to rank 0 and the un-tiling into the Film layout.  The frame is FIXED
+as N grows (the image is tiled across the GPUs), so scaling is "strong".
+Rays = ray segments for which a closest-hit query ran, counted on the device.
+The scene, BVH and path state are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+NODE_BYTES = 64        # one BVH2 node visit: two child AABBs + two child refs (csrc/bvh.h)
+TRI_BYTES = 48         # one leaf triangle test: 3 x float4 (P0+prim, P1+material, P2)
+RAY_FIXED_BYTES = 36   # k_intersect per ray: origin+dir read (2 x 16 B) + hit id write (4 B)
+PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md §8d)")
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--samples-in-flight", type=int, default=0, help="0 = auto")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump", default="", help="write the final frame as PPM/PFM with this path prefix")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+    g.build(quiet=True)
+    import parallelraytracing_amd as prt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    # ---- workload (outside the timed region: PLY parse, refinement, BVH build, upload) ----
+    t_setup = time.time()
+    scene, cam, W, H, spp_total, max_depth = prt.scenes.config(args.config)
+    film = prt.Film(W, H)
+    r = prt.HipWavefrontRenderer(device=local_rank, max_depth=max_depth, seed=0, rank=rank, world_size=world)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.Init(film, scene, cam)
+    r.set_variant(args.variant)
+    n_tris = scene.n_triangles
+    bvh = r.bvh_info()
+    spp_step = args.spp_per_step
+    sif = args.samples_in_flight or min(spp_step, max(1, (4 * 1920 * 1080 * world) // (W * H)))
+    sif = max(1, min(sif, spp_step))
+    r.set_samples_in_flight(sif)
+    gather = prt.dist.FilmGather(r, device)
+    setup_s = time.time() - t_setup
+
+    # algorithmic traffic of the dominant kernel, measured with the instrumented traversal on sample 0
+    trav = r.measure_traversal(sample=0)
+    rays_sample = int(trav.rays_total)
+    alg_bytes_sample = (NODE_BYTES * int(trav.bvh_node_visits) + TRI_BYTES * int(trav.bvh_tri_tests)
+                        + PRIM_BYTES * int(trav.prim_tests) + RAY_FIXED_BYTES * rays_sample)
+
+    def step():
+        r.render_async(spp_step)
+        gather()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    r.reset_stats()
+    r.enable_timing(not args.no_kernel_timing)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r.enable_timing(False)
+    st = r.stats()
+    rays_local = int(st.rays_total)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([rays_local], dtype=torch.int64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rays_total = int(c.item())
+    else:
+        rays_total = rays_local
+
+    value = rays_total / dt / 1e6
+
+    # ---- roofline of the dominant kernel (k_intersect), this rank ----
+    roofline = None
+    if not args.no_kernel_timing and st.intersect_launches:
+        avg_ms = st.intersect_ms / st.intersect_launches
+        # measure_traversal ran on THIS rank's tiles, so alg_bytes_sample is already the local share of one
+        # sample; a launch is one depth of one batch of `sif` samples: bytes/launch = total bytes / launches
+        bytes_per_launch = alg_bytes_sample * st.samples / st.intersect_launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_intersect",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
+                    "alg_bytes_per_launch": int(bytes_per_launch),
+                    "node_visits_per_ray": round(trav.bvh_node_visits / max(1, rays_sample), 2),
+                    "tri_tests_per_ray": round(trav.bvh_tri_tests / max(1, rays_sample), 2),
+                    "stage_ms": {"raygen": round(st.raygen_ms, 3), "intersect": round(st.intersect_ms, 3),
+                                 "shade": round(st.shade_ms, 3), "accumulate": round(st.accumulate_ms, 3)}}
+
+    # ---- CPU baseline: the oracle, timed on this box's host cores on a bounded sample (rank 0, N = 1) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        # the GPU box gives one GPU slot a share of 16 host cores; PRT_CPU_THREADS overrides
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = int(os.environ.get("PRT_CPU_THREADS", min(avail, 16)))
+        osc = orc.OracleScene(scene.desc())
+        cd = cam.desc()
+        # calibrate on a thin strip, then size the sample (rows of the frame, or whole frames) for ~cpu_seconds
+        y0 = H // 2
+        tc = time.perf_counter()
+        _, _, rays_c = osc.render(cd, W, H, spp=1, max_depth=max_depth, seed=0, iterative=False, use_bvh=True,
+                                  n_threads=cores, rect=(0, y0 - 8, W, y0 + 8))
+        tcal = max(time.perf_counter() - tc, 1e-6)
+        frame_s = tcal * H / 16.0  # estimated seconds for one full-frame sample
+        if frame_s > args.cpu_seconds:
+            rows, spp_c = max(16, int(H * args.cpu_seconds / frame_s)), 1
+        else:
+            rows, spp_c = H, max(1, min(64, int(args.cpu_seconds / frame_s)))
+        ya = max(0, (H - rows) // 2)
+        tc = time.perf_counter()
+        _, _, rays_b = osc.render(cd, W, H, spp=spp_c, max_depth=max_depth, seed=0, iterative=False, use_bvh=True,
+                                  n_threads=cores, rect=(0, ya, W, ya + rows))
+        tb = time.perf_counter() - tc
+        cpu = {"value": round(rays_b / tb / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"{args.config} rows {ya}..{ya + rows} of {H} at {spp_c} spp ({rays_b} rays, {tb:.1f} s, "
+                         f"{cores} threads); oracle = CPU restatement of the reference CPU backend (recursive TraceRay) "
+                         "using the oracle's own median-split BVH for the mesh; the reference itself has no BVH "
+                         "(linear scan over all primitives) and is unbuildable here"}
+
+    if args.dump and rank == 0:
+        rgb, wts = gather()
+        torch.cuda.synchronize()
+        a = rgb.cpu().numpy().reshape(H, W, 3)
+        w = wts.cpu().numpy().reshape(H, W)
+        mean = np.where(w[..., None] > 0, a / np.maximum(w[..., None], 1e-30), 0).astype(np.float32)
+        prt.write_pfm(args.dump + ".pfm", mean)
+        rgba = torch.empty(H * W * 4, dtype=torch.uint8, device=device)
+        r.film_tonemap(rgb.data_ptr(), wts.data_ptr(), rgba.data_ptr())
+        r.synchronize()
+        prt.write_ppm(args.dump + ".ppm", rgba.cpu().numpy().reshape(H, W, 4))
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec at 1920x1080, 4 bounces, ~1M-tri scene",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: dragon.ply refined to {n_tris} triangles + ground quad + emissive quad, "
+                                   f"{W}x{H}, max_depth {max_depth} segments (= {max_depth - 1} bounces), "
+                                   f"{spp_step} spp per step ({args.steps * spp_step} spp timed of the config's {spp_total}), "
+                                   f"image tiled over {world} GPU(s) + per-step gather to rank 0",
+                       "triangles": n_tris, "bvh_nodes": int(bvh.n_nodes), "bvh_max_depth": int(bvh.max_depth),
+                       "width": W, "height": H, "max_depth": max_depth, "spp_per_step": spp_step,
+                       "samples_in_flight": sif, "seed": 0, "rays_timed": rays_total,
+                       "rays_per_sample": rays_sample, "setup_s": round(setup_s, 2), "variant": args.variant},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

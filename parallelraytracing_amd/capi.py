@@ -132,6 +132,12 @@ def load(path: str = LIB_PATH) -> C.CDLL:
             f"{path} is missing: the HIP extension is the product and has no fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C parallelraytracing_amd/csrc`).")
+    # torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process do
+    # not coexist, so when torch is importable it must load first (libprt.so then binds to the same runtime).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing only: the library also runs without it (system ROCm runtime)
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -235,49 +235,47 @@ PRT_DEV f3 refract3(f3 uv, f3 n, float eta) {
 }
 
 // MaterialHandle::Emit + Scatter (material.h:139-161).  out_d is NOT normalised (the caller does,
-// src/backend/cpu/renderer.cpp:84).
+// src/backend/cpu/renderer.cpp:84).  Written with selects instead of nested branches: the three
+// scattering materials share the tail, and the dielectric evaluates both reflect and refract.
 PRT_DEV bool material_scatter(uint32_t type, float4 rgbs, f3 in_d, f3 pos, f3 normal, bool front, uint32_t& rng,
                               f3& atten, f3& emitted, f3& out_o, f3& out_d) {
-    emitted = mk3(0.0f, 0.0f, 0.0f);
-    atten = mk3(0.0f, 0.0f, 0.0f);
-    out_o = mk3(0.0f, 0.0f, 0.0f);
+    const f3 rgb = mk3(rgbs.x, rgbs.y, rgbs.z);
+    const f3 zero = mk3(0.0f, 0.0f, 0.0f);
+    emitted = (type == 4u) ? rgb : zero;  // Emissive::Emit (material.h:124-127); everything else emits 0
+    const bool scattering = (type >= 1u && type <= 3u);
+    out_o = scattering ? pos : zero;
+    atten = zero;
     out_d = mk3(0.0f, 0.0f, 1.0f);
+    bool result = false;
     if (type == 1u) {  // Lambertian (material.h:16-31)
         f3 dir = normal + random_unit_vector(rng);
         const double s = 1e-8;
         if (((double)__builtin_fabsf(dir.x) < s) && ((double)__builtin_fabsf(dir.y) < s) &&
             ((double)__builtin_fabsf(dir.z) < s))
             dir = normal;
-        out_o = pos;
         out_d = normalize3(dir);
-        atten = mk3(rgbs.x, rgbs.y, rgbs.z);
-        return true;
-    }
-    if (type == 2u) {  // Metal (material.h:48-57)
+        atten = rgb;
+        result = true;
+    } else if (type == 2u) {  // Metal (material.h:48-57): the RNG is drawn even when roughness == 0
         f3 r = reflect3(in_d, normal);
         r = normalize3(r) + rgbs.w * random_unit_vector(rng);
-        out_o = pos;
         out_d = normalize3(r);
-        atten = mk3(rgbs.x, rgbs.y, rgbs.z);
-        return dot3(out_d, normal) > 0.0f;
-    }
-    if (type == 3u) {  // Dielectric (material.h:76-95)
+        atten = rgb;
+        result = dot3(out_d, normal) > 0.0f;
+    } else if (type == 3u) {  // Dielectric (material.h:76-95)
         atten = mk3(1.0f, 1.0f, 1.0f);
-        float ri = front ? (1.0f / rgbs.w) : rgbs.w;
-        float cos_theta = glm_min(dot3(-in_d, normal), 1.0f);
-        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
-        bool cannot = ri * sin_theta > 1.0f;
-        f3 dir;
-        if (cannot || fresnel_reflectance(cos_theta, ri) > rnd01(rng))
-            dir = reflect3(in_d, normal);
-        else
-            dir = refract3(in_d, normal, ri);
-        out_o = pos;
-        out_d = dir;
-        return true;
+        const float ri = front ? (1.0f / rgbs.w) : rgbs.w;
+        const float cos_theta = glm_min(dot3(-in_d, normal), 1.0f);
+        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        const bool cannot = ri * sin_theta > 1.0f;
+        bool do_reflect = cannot;
+        if (!cannot) do_reflect = fresnel_reflectance(cos_theta, ri) > rnd01(rng);  // RNG drawn only if it can refract
+        const f3 refl = reflect3(in_d, normal);
+        const f3 refr = refract3(in_d, normal, ri);
+        out_d = do_reflect ? refl : refr;
+        result = true;
     }
-    if (type == 4u) emitted = mk3(rgbs.x, rgbs.y, rgbs.z);  // Emissive (material.h:114-127)
-    return false;
+    return result;
 }
 
 // Camera::GetCameraRay (src/core/camera.h:103-132)
