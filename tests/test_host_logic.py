@@ -1,0 +1,342 @@
+"""CPU-side tests of the product's host logic (no GPU): the C-ABI library loads and exports every symbol the
+header declares, compute entry points fail loudly without a device, presets / transforms agree with the
+oracle bit for bit, PLY ingest, mesh refinement, BVH construction, tile maps, framebuffer dumps."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from util import orc, prt
+
+capi = prt.capi
+
+
+# ---- the boundary ---------------------------------------------------------------------------------------------------
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(util.ROOT, "include", "prt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(prt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = C.CDLL(capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/prt.h but not exported by libprt.so"
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    assert capi.lib().prt_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(capi.PrtMaterial) == 20 and C.sizeof(capi.PrtPrimitive) == 144
+    assert C.sizeof(capi.PrtHit) == 40 and np.dtype(capi.HIT_DTYPE).itemsize == 40
+    assert C.sizeof(capi.PrtCameraDesc) == 32
+    assert C.sizeof(capi.PrtStats) == 8 * (1 + 64 + 2) + 8 * 4 + 8 * 3
+
+
+def test_compute_fails_loudly_without_a_device():
+    """No CPU fallback: on a box without a GPU every compute entry point must return an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(prt.PrtError, match="no HIP device"):
+        prt.HipWavefrontRenderer(device=0)
+    r = prt.HipWavefrontRenderer(device=-1)  # host-only context: utilities only
+    r.set_scene_host_only(prt.Scene("CORNELL"))
+    with pytest.raises(prt.PrtError, match="no CPU fallback"):
+        r.ProgressiveRender()
+    with pytest.raises(prt.PrtError, match="no CPU fallback"):
+        r.closest_hit(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32))
+    with pytest.raises(prt.PrtError):
+        r.stats()
+
+
+def test_scene_validation_errors():
+    r = prt.HipWavefrontRenderer(device=-1)
+    bad = prt.Scene(preset=None)
+    bad.AddQuad(1, 1, material=0)  # no materials at all
+    with pytest.raises(prt.PrtError, match="material out of range"):
+        r.set_scene_host_only(bad)
+    with pytest.raises(prt.PrtError):
+        prt.Mesh(vertices=np.zeros((3, 3), np.float32), indices=np.array([[0, 1, 7]], np.uint32))
+
+
+# ---- presets / transforms: product host code == oracle restatement, bit for bit -------------------------------------
+@pytest.mark.parametrize("name", list(capi.PRESET_NAMES))
+def test_presets_match_oracle_bitwise(name):
+    sc = prt.Scene(name)
+    mats, prims = orc.scene_preset(capi.PRESET_NAMES[name])
+    assert len(sc.materials) == len(mats) and len(sc.primitives) == len(prims)
+    assert b"".join(bytes(m) for m in sc.materials) == bytes(mats)
+    assert b"".join(bytes(p) for p in sc.primitives) == bytes(prims)
+
+
+def test_make_transform_matches_oracle_bitwise():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        s = rng.uniform(0.2, 3.0, 3)
+        e = rng.uniform(-180, 180, 3)
+        t = rng.uniform(-40, 40, 3)
+        m1, i1 = prt.make_transform(s, e, t)
+        m2, i2 = orc.make_transform(s, e, t)
+        assert np.array_equal(m1, m2) and np.array_equal(i1, i2)
+        assert np.allclose(i1.reshape(4, 4).T @ m1.reshape(4, 4).T, np.eye(4), atol=1e-4)
+
+
+def test_default_camera_is_mains_camera():
+    c = prt.Camera()  # src/main.cpp:142-150
+    assert c.position == (5.0, 5.0, 8.0) and (c.width, c.height) == (1920.0, 1080.0)
+    assert np.allclose(c.front, -np.array([5, 5, 8]) / np.sqrt(114.0), atol=1e-7)
+
+
+# ---- PLY ingest (mesh.cpp:79-97,113-144) ------------------------------------------------------------------------------
+def test_ply_counts_match_the_file_headers():
+    for name, nv, nt, has_n in [("bunny.ply", 5002, 10000, True), ("dragon.ply", 10000, 20000, True),
+                                ("icosahedron.ply", 12, 20, True), ("hand.ply", 5502, 11000, False),
+                                ("cube_uv.ply", 24, 12, True)]:  # 6 quads -> 12 triangles
+        m = prt.Mesh(prt.scenes.asset(name))
+        assert (m.n_vertices, m.n_triangles, m.had_normals) == (nv, nt, has_n), name
+        assert m.GetIndices().max() < nv
+        n = np.linalg.norm(m.GetNormals(), axis=1)
+        if name == "icosahedron.ply":  # the file stores un-normalised normals (|n| = 4.16); ingest keeps file data
+            assert np.allclose(n, n[0], rtol=1e-4)
+        else:
+            assert np.allclose(n, 1.0, atol=1e-3), name
+
+
+def test_binary_ply_values():
+    m = prt.Mesh(prt.scenes.asset("icosahedron.ply"))  # binary_little_endian
+    v = m.GetVertices()
+    assert np.array_equal(v[0], np.float32([0, 0, -1]))
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-5)
+    n = m.GetNormals()
+    assert np.allclose(n / np.linalg.norm(n, axis=1, keepdims=True), v, atol=1e-4)  # radial normals
+
+
+def test_ascii_and_binary_round_trip(tmp_path):
+    v = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    f = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]], np.int32)
+    p_ascii = tmp_path / "t.ply"
+    with open(p_ascii, "w") as fh:
+        fh.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 4\nproperty float x\nproperty float y\n"
+                 "property float z\nproperty uchar red\nelement face 4\nproperty list uchar int vertex_indices\n"
+                 "end_header\n")
+        for r in v:
+            fh.write("%g %g %g 7\n" % tuple(r))
+        for r in f:
+            fh.write("3 %d %d %d\n" % tuple(r))
+    p_bin = tmp_path / "b.ply"
+    with open(p_bin, "wb") as fh:
+        fh.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty double x\nproperty double y\n"
+                 b"property double z\nelement face 4\nproperty list uchar ushort vertex_indices\nend_header\n")
+        fh.write(v.astype("<f8").tobytes())
+        for r in f:
+            fh.write(bytes([3]) + r.astype("<u2").tobytes())
+    for p in (p_ascii, p_bin):
+        m = prt.Mesh(str(p))
+        assert np.array_equal(m.GetVertices(), v) and np.array_equal(m.GetIndices(), f.astype(np.uint32))
+        assert not m.had_normals and np.allclose(np.linalg.norm(m.GetNormals(), axis=1), 1.0, atol=1e-6)
+
+
+def test_ply_errors(tmp_path):
+    with pytest.raises(prt.PrtError, match="cannot open"):
+        prt.Mesh(str(tmp_path / "missing.ply"))
+    p = tmp_path / "bad.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+                 "end_header\n0 0 0\n")
+    with pytest.raises(prt.PrtError, match="truncated"):
+        prt.Mesh(str(p))
+    p.write_text("plx\n")
+    with pytest.raises(prt.PrtError, match="not a PLY"):
+        prt.Mesh(str(p))
+    p.write_text("ply\nformat binary_big_endian 1.0\nend_header\n")
+    with pytest.raises(prt.PrtError, match="unsupported"):
+        prt.Mesh(str(p))
+
+
+# ---- refinement ----------------------------------------------------------------------------------------------------------
+def _edge_counts(idx):
+    e = np.concatenate([idx[:, [0, 1]], idx[:, [1, 2]], idx[:, [2, 0]]])
+    e = np.sort(e, axis=1)
+    _, c = np.unique(e, axis=0, return_counts=True)
+    return c
+
+
+def test_refine_hits_exact_target_and_stays_a_closed_manifold():
+    m = prt.Mesh(prt.scenes.asset("bunny.ply"))
+    assert (_edge_counts(m.GetIndices()) == 2).all()
+    m.refine(70_000)
+    idx, v = m.GetIndices(), m.GetVertices()
+    assert m.n_triangles == 70_000 and (_edge_counts(idx) == 2).all()
+    assert m.n_vertices - (3 * m.n_triangles // 2) + m.n_triangles == 5002 - 15000 + 10000  # Euler characteristic kept
+    assert np.abs(v).max() <= 1.0 + 1e-6 and np.allclose(np.linalg.norm(m.GetNormals(), axis=1), 1, atol=1e-3)
+    # longest-edge bisection makes edges shorter, never longer
+    e = np.linalg.norm(v[idx[:, 0]] - v[idx[:, 1]], axis=1)
+    assert e.max() < 0.06
+
+
+def test_refine_is_deterministic_and_preserves_area():
+    def area(m):
+        v, i = m.GetVertices().astype(np.float64), m.GetIndices()
+        return 0.5 * np.linalg.norm(np.cross(v[i[:, 1]] - v[i[:, 0]], v[i[:, 2]] - v[i[:, 0]]), axis=1).sum()
+    a = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
+    a0 = area(a)
+    a.refine(3000)
+    b = prt.Mesh(prt.scenes.asset("icosahedron.ply")).refine(3000)
+    assert np.array_equal(a.GetVertices(), b.GetVertices()) and np.array_equal(a.GetIndices(), b.GetIndices())
+    assert abs(area(a) - a0) < 1e-4 * a0  # midpoints lie on the old edges: the surface is unchanged
+
+
+def test_mesh_transform_and_append():
+    m = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
+    v0, n0 = m.GetVertices(), m.GetNormals()
+    mat, inv = prt.make_transform((2, 2, 2), (90, 0, 0), (1, 2, 3))
+    m2 = m.copy().transform(mat, inv)
+    want = np.stack([orc.transform_point(mat, p) for p in v0])
+    assert np.array_equal(m2.GetVertices(), want)
+    wn = np.stack([orc.transform_normal(inv, p) for p in n0])
+    assert np.array_equal(m2.GetNormals(), wn)
+    m.append(m2)
+    assert m.n_vertices == 24 and m.n_triangles == 40 and m.GetIndices()[20:].min() == 12
+
+
+# ---- BVH construction (host) ---------------------------------------------------------------------------------------------
+def _leaf_ranges(nodes):
+    refs = nodes[:, 12:14].view(np.int32)
+    out = []
+    for node in range(len(nodes)):
+        for side in range(2):
+            r = int(refs[node, side])
+            if r < 0:
+                u = (~r) & 0xFFFFFFFF
+                out.append((node, side, u >> 4, u & 15))
+    return out, refs
+
+
+@pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("dragon.ply", 60_000)])
+def test_bvh_structure(ply, target):
+    mesh = prt.Mesh(prt.scenes.asset(ply))
+    if target:
+        mesh.refine(target)
+    sc = prt.scenes.mesh_scene(mesh)
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    info = r.bvh_info()
+    nodes, tris = r.bvh_read()
+    nt = mesh.n_triangles
+    assert info.n_triangles == nt and info.max_leaf_size <= 4 and info.max_depth <= 64
+    leaves, refs = _leaf_ranges(nodes)
+    covered = np.zeros(nt, np.int32)
+    for node, side, first, cnt in leaves:
+        covered[first:first + cnt] += 1
+        box = nodes[node, 0:6] if side == 0 else nodes[node, 6:12]
+        P = tris[first:first + cnt].reshape(cnt, 3, 4)[:, :, :3].reshape(-1, 3)
+        if cnt:
+            assert (P >= box[:3]).all() and (P <= box[3:]).all()
+    assert (covered == 1).all()  # every triangle slot is in exactly one leaf
+    # every internal node is referenced exactly once (node 0 is the root)
+    child = refs[refs >= 0]
+    assert sorted(child.tolist()) == list(range(1, len(nodes)))
+    # a child's boxes are inside the box its parent stores for it
+    for node in range(len(nodes)):
+        for side in range(2):
+            c = int(refs[node, side])
+            if c >= 0:
+                pb = nodes[node, 0:6] if side == 0 else nodes[node, 6:12]
+                lo = np.minimum(nodes[c, 0:3], nodes[c, 6:9])
+                hi = np.maximum(nodes[c, 3:6], nodes[c, 9:12])
+                assert (lo >= pb[:3]).all() and (hi <= pb[3:]).all()
+    # triangle records: global prim index = n_analytic + input triangle index, a permutation
+    prim = tris[:, 3].view(np.uint32).astype(np.int64) - len(sc.primitives)
+    assert sorted(prim.tolist()) == list(range(nt))
+    v, idx = mesh.GetVertices(), mesh.GetIndices()
+    k = np.arange(0, nt, max(1, nt // 500))
+    assert np.array_equal(tris[k].reshape(-1, 3, 4)[:, :, :3], v[idx[prim[k]]])
+    assert (tris[:, 7].view(np.uint32) == 2).all()  # material id of mesh_scene's body
+
+
+def test_bvh_single_triangle_and_empty_scene():
+    r = prt.HipWavefrontRenderer(device=-1)
+    one = prt.Mesh(vertices=np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), indices=np.array([[0, 1, 2]], np.uint32))
+    sc = prt.Scene(preset=None)
+    sc.AddMesh(one, sc.AddLambertian((1, 1, 1)))
+    r.set_scene_host_only(sc)
+    nodes, tris = r.bvh_read()
+    leaves, _ = _leaf_ranges(nodes)
+    assert len(nodes) == 1 and sorted((f, c) for _, _, f, c in leaves) == [(0, 0), (0, 1)]
+    r.set_scene_host_only(prt.Scene("CORNELL"))
+    assert r.bvh_info().n_nodes == 0 and r.bvh_info().n_triangles == 0
+
+
+def test_bvh_python_traversal_agrees_with_oracle_linear_scan():
+    """Walk the product's BVH in numpy (exact boxes, generous slack) and check that the set of leaves a ray
+    reaches always contains the triangle the oracle's linear scan picks."""
+    mesh = prt.Mesh(prt.scenes.asset("bunny.ply"))
+    sc = prt.Scene(preset=None)
+    sc.AddMesh(mesh, sc.AddLambertian((1, 1, 1)))
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    nodes, tris = r.bvh_read()
+    refs = nodes[:, 12:14].view(np.int32)
+    prim_of_slot = tris[:, 3].view(np.uint32)
+    rng = np.random.default_rng(3)
+    o, d = util.random_rays(rng, 150, center=(0, 0, 0), radius=6.0, spread=0.8)
+    want = util.oracle_scene(sc).closest_hit(o, d, use_bvh=False, n_threads=8)
+    assert (want["prim"] >= 0).sum() > 60
+    for k in range(len(o)):
+        if want["prim"][k] < 0:
+            continue
+        inv = 1.0 / np.where(np.abs(d[k]) < 1e-20, 1e-20, d[k]).astype(np.float64)
+        reached = set()
+        stack = [0]
+        while stack:
+            n = stack.pop()
+            for side in range(2):
+                b = nodes[n, 0:6] if side == 0 else nodes[n, 6:12]
+                t0 = (b[:3] - 1e-4 - o[k]) * inv
+                t1 = (b[3:] + 1e-4 - o[k]) * inv
+                tn = max(np.minimum(t0, t1).max(), 0.0)
+                tf = np.maximum(t0, t1).min()
+                if tn <= tf:
+                    c = int(refs[n, side])
+                    if c >= 0:
+                        stack.append(c)
+                    else:
+                        u = (~c) & 0xFFFFFFFF
+                        reached.update(prim_of_slot[(u >> 4):(u >> 4) + (u & 15)].tolist())
+        assert int(want["prim"][k]) in reached
+
+
+# ---- tile map / partition (dist.py restates the kernels' tile layout) ---------------------------------------------------
+@pytest.mark.parametrize("W,H,world", [(64, 48, 1), (100, 52, 3), (37, 19, 2), (1920, 1080, 8), (8, 8, 4)])
+def test_tile_partition_covers_every_pixel_once(W, H, world):
+    tx, ty, stride = prt.dist.tile_layout(W, H, world)
+    owner, slot = prt.dist.pixel_owner_and_slot(W, H, world)
+    assert owner.min() >= 0 and owner.max() < world and slot.max() < stride
+    key = owner * stride + slot
+    assert len(np.unique(key)) == W * H
+    counts = np.bincount(owner.ravel(), minlength=world)
+    assert counts.max() - counts.min() <= 64 * (1 + (tx * ty) % world != 0) * 64  # balanced to within a few tiles
+    rng = np.random.default_rng(W)
+    acc = rng.random((H, W, 3)).astype(np.float32)
+    wts = rng.random((H, W)).astype(np.float32)
+    g = np.stack([prt.dist.pack_tiles_numpy(acc, wts, r, world) for r in range(world)])
+    a2, w2 = prt.dist.untile_numpy(g, W, H)
+    assert np.array_equal(a2, acc) and np.array_equal(w2, wts)
+
+
+# ---- framebuffer dumps ------------------------------------------------------------------------------------------------------
+def test_ppm_and_pfm_dumps(tmp_path):
+    rgba = np.zeros((3, 4, 4), np.uint8)
+    rgba[0, :, 0] = 255  # top row red
+    rgba[..., 3] = 255
+    prt.write_ppm(str(tmp_path / "a.ppm"), rgba)
+    raw = open(tmp_path / "a.ppm", "rb").read()
+    assert raw.startswith(b"P6\n4 3\n255\n") and raw[11:14] == bytes([255, 0, 0]) and len(raw) == 11 + 36
+    rgb = np.arange(3 * 4 * 3, dtype=np.float32).reshape(3, 4, 3)
+    prt.write_pfm(str(tmp_path / "a.pfm"), rgb)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    hdr = b"PF\n4 3\n-1.0\n"
+    assert raw.startswith(hdr)
+    body = np.frombuffer(raw[len(hdr):], "<f4").reshape(3, 4, 3)
+    assert np.array_equal(body[::-1], rgb)  # PFM stores the bottom row first; film row 0 is the top
