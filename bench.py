@@ -35,10 +35,10 @@ PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md §8d)")
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="0 = auto")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +82,8 @@ def main():
     n_tris = scene.n_triangles
     bvh = r.bvh_info()
     spp_step = args.spp_per_step
-    sif = args.samples_in_flight or min(spp_step, max(1, (4 * 1920 * 1080 * world) // (W * H)))
+    # many samples in flight: the late bounces are latency/tail-bound, more rays per launch hide it (288 GB HBM)
+    sif = args.samples_in_flight or min(spp_step, max(1, (32 * 1920 * 1080 * world) // (W * H)))
     sif = max(1, min(sif, spp_step))
     r.set_samples_in_flight(sif)
     gather = prt.dist.FilmGather(r, device)

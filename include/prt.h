@@ -133,6 +133,8 @@ typedef struct PrtStats {
     uint64_t bvh_node_visits;          /* only from prt_measure_traversal */
     uint64_t bvh_tri_tests;
     uint64_t prim_tests;
+    uint64_t node_lane_slots;          /* 64 x node-loop iterations of all waves: visits / slots = lane efficiency */
+    double scan_ms;                    /* analytic-primitive scan kernel (default variant) */
 } PrtStats;
 
 typedef struct PrtBvhInfo {
@@ -218,6 +220,8 @@ int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
 int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);
 /* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
 int prt_set_variant(PrtContext* ctx, int variant);
+/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "stack_lds". */
+int prt_set_param(PrtContext* ctx, const char* name, int value);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */
 /* PLY ingest with the subset the reference's Mesh asks tinyply for (src/core/mesh.cpp:79-97,113-144):

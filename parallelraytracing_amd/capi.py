@@ -59,7 +59,8 @@ class PrtStats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_per_depth", C.c_uint64 * PRT_MAX_DEPTH), ("samples", C.c_uint64),
                 ("intersect_launches", C.c_uint64), ("intersect_ms", C.c_double), ("shade_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("bvh_node_visits", C.c_uint64),
-                ("bvh_tri_tests", C.c_uint64), ("prim_tests", C.c_uint64)]
+                ("bvh_tri_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("node_lane_slots", C.c_uint64),
+                ("scan_ms", C.c_double)]
 
 
 class PrtBvhInfo(C.Structure):
@@ -107,6 +108,7 @@ SIGNATURES = {
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_set_variant": (C.c_int, [_vp, C.c_int]),
+    "prt_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "prt_mesh_load_ply": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_size_t]),
     "prt_mesh_create": (C.c_int, [_fp, _fp, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_vp)]),
     "prt_mesh_free": (None, [_vp]),

@@ -24,11 +24,11 @@ namespace {
 
 constexpr float kPadCoeff = 1.0f / 262144.0f;  // 2^-18, see traverse() in prt_kernels.hip
 constexpr uint32_t kMaxLeaf = 4;
-constexpr uint32_t kMaxStack = 64;
+constexpr uint32_t kMaxStack = 63;  // LDS stack entries per lane: 31 (5 blocks/CU) or 63 (2 blocks/CU)
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;  // 0 raygen, 1 intersect, 2 shade, 3 accumulate
+    int kind;  // 0 raygen, 1 intersect (dominant kernel), 2 shade, 3 accumulate, 4 analytic-primitive scan
 };
 
 }  // namespace
@@ -71,6 +71,7 @@ struct PrtContext {
     uint64_t cap_paths = 0;
     PrtRayBuf rb[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     uint32_t* d_hit = nullptr;
+    float* d_hd2 = nullptr;
     float4* d_rad = nullptr;
     uint32_t* d_counts = nullptr;             // PRT_MAX_DEPTH + 1
     unsigned long long* d_ray_stats = nullptr;  // PRT_MAX_DEPTH
@@ -87,6 +88,10 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
+    PrtTravTuning tune{1280u, 256u, 16u, 16u, 31u};  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
+    uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
+    uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
+    size_t spill_entries = 0;
 };
 
 namespace {
@@ -138,6 +143,7 @@ void free_path_state(PrtContext* c) {
         free_dev(c->rb[i].t);
     }
     free_dev(c->d_hit);
+    free_dev(c->d_hd2);
     free_dev(c->d_rad);
     c->cap_paths = 0;
 }
@@ -152,6 +158,7 @@ int ensure_path_state(PrtContext* c, uint64_t n_paths) {
         HIPCHECK(c, hipMalloc((void**)&c->rb[i].t, n * sizeof(float4)));
     }
     HIPCHECK(c, hipMalloc((void**)&c->d_hit, n * sizeof(uint32_t)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_hd2, n * sizeof(float)));
     HIPCHECK(c, hipMalloc((void**)&c->d_rad, n * sizeof(float4)));
     c->cap_paths = n;
     return PRT_OK;
@@ -165,6 +172,19 @@ int ensure_counters(PrtContext* c) {
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_work, 64));
+    HIPCHECK(c, hipMemset(c->d_work, 0, 64));
+    return PRT_OK;
+}
+
+// global spill area of the traversal stacks: [63 - stack_lds entries][grid threads]
+int ensure_spill(PrtContext* c) {
+    const size_t need = (size_t)c->tune.grid_blocks * 256u * 64u;
+    if (need <= c->spill_entries) return PRT_OK;
+    free_dev(c->d_spill);
+    c->spill_entries = 0;
+    HIPCHECK(c, hipMalloc((void**)&c->d_spill, need * sizeof(uint32_t)));
+    c->spill_entries = need;
     return PRT_OK;
 }
 
@@ -216,6 +236,7 @@ int drain_events(PrtContext* c) {
             case 0: c->stats.raygen_ms += ms; break;
             case 1: c->stats.intersect_ms += ms; break;
             case 2: c->stats.shade_ms += ms; break;
+            case 4: c->stats.scan_ms += ms; break;
             default: c->stats.accumulate_ms += ms; break;
         }
         c->event_pool.push_back(ep);
@@ -246,7 +267,8 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     const uint32_t n_paths = (uint32_t)n_paths64;
     int rc = ensure_path_state(c, n_paths);
     if (rc) return rc;
-    const int stack_depth = c->bvh.max_depth <= 32 ? 32 : 64;
+    const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
+    if ((rc = ensure_spill(c))) return rc;
     EventPair ep{};
     if ((rc = begin_event(c, 0, &ep))) return rc;
     prt_launch_raygen(c->stream, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts, max_depth);
@@ -254,10 +276,23 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     for (uint32_t d = 0; d < max_depth; ++d) {
         const PrtRayBuf& in = c->rb[d & 1];
         const PrtRayBuf& out = c->rb[(d + 1) & 1];
-        if ((rc = begin_event(c, 1, &ep))) return rc;
-        prt_launch_intersect(c->stream, c->dsc, in, c->d_hit, c->d_counts + d, n_paths, stack_depth, c->variant,
-                             trav_stats);
-        if ((rc = end_event(c, &ep))) return rc;
+        if (c->variant == 0) {
+            // default: coherent scan of the analytic primitives, then persistent BVH traversal
+            if ((rc = begin_event(c, 4, &ep))) return rc;
+            prt_launch_scan_prims(c->stream, c->dsc, in, c->d_hit, c->d_hd2, c->d_counts + d, c->d_work, n_paths, trav_stats);
+            if ((rc = end_event(c, &ep))) return rc;
+            if (c->dsc.n_nodes) {
+                if ((rc = begin_event(c, 1, &ep))) return rc;
+                prt_launch_traverse(c->stream, c->dsc, in, c->d_hit, c->d_hd2, c->d_counts + d, c->d_work, c->d_spill,
+                                    n_paths, c->bvh.max_depth, c->tune, trav_stats);
+                if ((rc = end_event(c, &ep))) return rc;
+            }
+        } else {
+            if ((rc = begin_event(c, 1, &ep))) return rc;
+            prt_launch_intersect(c->stream, c->dsc, in, c->d_hit, c->d_counts + d, n_paths, stack_depth, c->variant,
+                                 trav_stats);
+            if ((rc = end_event(c, &ep))) return rc;
+        }
         ++c->stats.intersect_launches;
         if ((rc = begin_event(c, 2, &ep))) return rc;
         prt_launch_shade(c->stream, c->dsc, in, c->d_hit, out, c->d_rad, c->d_counts, d, max_depth, n_paths);
@@ -319,6 +354,8 @@ void prt_destroy(PrtContext* c) {
         free_dev(c->d_counts);
         free_dev(c->d_ray_stats);
         free_dev(c->d_trav_stats);
+        free_dev(c->d_work);
+        free_dev(c->d_spill);
         free_dev(c->d_scratch);
         for (EventPair& ep : c->events) {
             (void)hipEventDestroy(ep.a);
@@ -555,6 +592,14 @@ int prt_synchronize(PrtContext* c) {
     int rc = need_device(c);
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_work) {  // watchdog flag of the persistent traversal kernel
+        uint32_t w[2] = {0, 0};
+        HIPCHECK(c, hipMemcpy(w, c->d_work, sizeof(w), hipMemcpyDeviceToHost));
+        if (w[1]) {
+            HIPCHECK(c, hipMemset(c->d_work, 0, 64));
+            return fail(c, PRT_ERR_HIP, "traversal watchdog tripped: a wave exceeded its iteration cap");
+        }
+    }
     return PRT_OK;
 }
 
@@ -688,8 +733,15 @@ int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float
     HIPCHECK(c, hipMemcpyAsync(d_d, dirs, b3, hipMemcpyHostToDevice, c->stream));
     uint32_t* cnt = c->d_counts + PRT_MAX_DEPTH + 1;  // a counter slot the render loop never uses
     prt_launch_pack_rays(c->stream, n, d_o, d_d, c->rb[0], cnt);
-    const int stack_depth = c->bvh.max_depth <= 32 ? 32 : 64;
-    prt_launch_intersect(c->stream, c->dsc, c->rb[0], c->d_hit, cnt, n, stack_depth, c->variant, nullptr);
+    const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
+    if (c->variant == 0) {
+        if ((rc = ensure_spill(c))) return rc;
+        prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, n, nullptr);
+        if (c->dsc.n_nodes)
+            prt_launch_traverse(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, c->d_spill, n, c->bvh.max_depth, c->tune, nullptr);
+    } else {
+        prt_launch_intersect(c->stream, c->dsc, c->rb[0], c->d_hit, cnt, n, stack_depth, c->variant, nullptr);
+    }
     prt_launch_hit_records(c->stream, c->dsc, n, c->rb[0], c->d_hit, d_h);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(hits, d_h, bh, hipMemcpyDeviceToHost, c->stream));
@@ -810,6 +862,7 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     out->bvh_node_visits = t[0];
     out->bvh_tri_tests = t[1];
     out->prim_tests = t[2];
+    out->node_lane_slots = t[3];
     return PRT_OK;
 }
 
@@ -825,6 +878,19 @@ int prt_bvh_read(PrtContext* c, float* nodes, float* tris) {
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
     if (nodes) memcpy(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4);
     if (tris) memcpy(tris, c->tri_records.data(), c->tri_records.size() * 4);
+    return PRT_OK;
+}
+
+int prt_set_param(PrtContext* c, const char* name, int value) {
+    if (!c || !name) return PRT_ERR_INVALID;
+    const std::string n = name;
+    if (n == "variant") c->variant = value;
+    else if (n == "grid_blocks" && value > 0 && value <= 8192) c->tune.grid_blocks = (uint32_t)value;
+    else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 24 || value == 31)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
+    else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;
+    else return fail(c, PRT_ERR_INVALID, "unknown parameter or bad value: %s = %d", name, value);
     return PRT_OK;
 }
 

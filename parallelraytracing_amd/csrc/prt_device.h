@@ -272,7 +272,7 @@ PRT_DEV bool material_scatter(uint32_t type, float4 rgbs, f3 in_d, f3 pos, f3 no
         if (!cannot) do_reflect = fresnel_reflectance(cos_theta, ri) > rnd01(rng);  // RNG drawn only if it can refract
         const f3 refl = reflect3(in_d, normal);
         const f3 refr = refract3(in_d, normal, ri);
-        out_d = do_reflect ? refl : refr;
+        out_d = mk3(do_reflect ? refl.x : refr.x, do_reflect ? refl.y : refr.y, do_reflect ? refl.z : refr.z);
         result = true;
     }
     return result;

@@ -46,6 +46,15 @@ struct PrtTileMap {
     uint32_t stride;         // ceil(tiles_total / world) * 64: per-rank payload (float4 units), equal on all ranks
 };
 
+// Tunables of k_traverse_persistent (prt_set_param).
+struct PrtTravTuning {
+    uint32_t grid_blocks;  // resident 256-thread blocks of the persistent grid
+    uint32_t chunk;        // rays a wave grabs per global atomic (multiple of 64)
+    uint32_t refill_min;   // idle lanes of a wave that trigger a refill
+    uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf
+    uint32_t stack_lds;    // per-lane stack entries kept in LDS: 31 (5 blocks/CU) or 24 (6 blocks/CU, trees of depth <= 24)
+};
+
 struct PrtRayBuf {
     float4* o;  // origin.xyz, path id
     float4* d;  // direction.xyz, rng state
@@ -55,6 +64,11 @@ struct PrtRayBuf {
 void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
                        uint32_t max_depth);
+void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, float* hd2,
+                           const uint32_t* count_ptr, uint32_t* work, uint32_t max_rays, unsigned long long* stats);
+void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
+                         const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
+                         uint32_t tree_depth, const PrtTravTuning& tune, unsigned long long* stats);
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
                           const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
                           unsigned long long* stats);

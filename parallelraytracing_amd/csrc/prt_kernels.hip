@@ -11,7 +11,7 @@
 //    pixel indices instead (renderer.cu:226-228).
 //  * the hit buffer is one u32 per ray slot (primitive id); the shade kernel re-derives position/normal
 //    with the same device function the traversal used, so nothing else crosses HBM.
-//  * wave64 ballot compaction into the next bounce's buffer: one atomic per wave.
+//  * wave64 ballot compaction into the next bounce's buffer: one atomic per 1024-thread block.
 #include "prt_kernels.h"
 
 #include "prt_device.h"
@@ -103,9 +103,10 @@ PRT_DEV float limit_from_d2(float d2, float pad) {
     return (d2 < 3.0e38f) ? __builtin_sqrtf(d2) * 1.0000153f + 4.0f * pad : 3.4e38f;
 }
 
+// Variant 1 (kept for A/B runs): one loop, each iteration is either a node step or a leaf, per lane.
 template <int STACK, bool STATS>
-PRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
-                      uint32_t& n_tris) {
+PRT_DEV void traverse_ifif(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
+                           uint32_t& n_tris) {
     // Triangles carry the identity Transform: local origin = o, local direction = normalize(d)
     // (TransformNormal, primitive.cpp:30).
     const f3 ld = normalize3(d);
@@ -191,7 +192,127 @@ PRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* s
     }
 }
 
+// Variant 0 (default): speculative while-while traversal (Aila & Laine) on wave64.  Each lane walks internal
+// nodes until it holds a leaf; the first leaf found is POSTPONED and the lane keeps walking, so the wave
+// leaves the node loop only when no lane is still searching (one ballot per step), and then all lanes test
+// their leaves together.  Node steps and triangle tests are therefore executed with far fewer idle lanes
+// than the one-loop form, where the two code paths alternate within a wave.
+#define NODE_DONE 0x7FFFFFFF
+#define LEAF_NONE 0x7FFFFFFE
+#define NEED_POP 0x7FFFFFFD
 template <int STACK, bool STATS>
+PRT_DEV void traverse_ww(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
+                         uint32_t& n_tris) {
+    const f3 ld = normalize3(d);  // TransformNormal(identity, d), primitive.cpp:30
+    const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+    const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+    const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+    const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+    const float ax = (o.x + pad) * ix, ay = (o.y + pad) * iy, az = (o.z + pad) * iz;
+    const float bx = (o.x - pad) * ix, by = (o.y - pad) * iy, bz = (o.z - pad) * iz;
+    float tlimit = limit_from_d2(best.d2, pad);
+    int sp = 0;
+    int node = 0;
+    int leaf = LEAF_NONE;
+    while (node != NODE_DONE) {
+        // ---- phase 1: internal nodes ----
+        while ((unsigned)node < 0x40000000u) {
+            const float4 q0 = sc.nodes[4 * (size_t)node + 0];
+            const float4 q1 = sc.nodes[4 * (size_t)node + 1];
+            const float4 q2 = sc.nodes[4 * (size_t)node + 2];
+            const float4 q3 = sc.nodes[4 * (size_t)node + 3];
+            if (STATS) ++n_nodes;
+            const float l0x = __builtin_fmaf(q0.x, ix, -ax), l1x = __builtin_fmaf(q0.w, ix, -bx);
+            const float l0y = __builtin_fmaf(q0.y, iy, -ay), l1y = __builtin_fmaf(q1.x, iy, -by);
+            const float l0z = __builtin_fmaf(q0.z, iz, -az), l1z = __builtin_fmaf(q1.y, iz, -bz);
+            const float r0x = __builtin_fmaf(q1.z, ix, -ax), r1x = __builtin_fmaf(q2.y, ix, -bx);
+            const float r0y = __builtin_fmaf(q1.w, iy, -ay), r1y = __builtin_fmaf(q2.z, iy, -by);
+            const float r0z = __builtin_fmaf(q2.x, iz, -az), r1z = __builtin_fmaf(q2.w, iz, -bz);
+            const float tnL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l0x, l1x), __builtin_fminf(l0y, l1y)),
+                                              __builtin_fmaxf(__builtin_fminf(l0z, l1z), 0.0f));
+            const float tfL = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l0x, l1x), __builtin_fmaxf(l0y, l1y)),
+                                              __builtin_fminf(__builtin_fmaxf(l0z, l1z), tlimit));
+            const float tnR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r0x, r1x), __builtin_fminf(r0y, r1y)),
+                                              __builtin_fmaxf(__builtin_fminf(r0z, r1z), 0.0f));
+            const float tfR = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r0x, r1x), __builtin_fmaxf(r0y, r1y)),
+                                              __builtin_fminf(__builtin_fmaxf(r0z, r1z), tlimit));
+            const bool hL = tnL <= tfL * 1.0000005f;
+            const bool hR = tnR <= tfR * 1.0000005f;
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            if (hL && hR) {
+                const bool lfirst = tnL <= tnR;
+                node = lfirst ? left : right;
+                const int farc = lfirst ? right : left;
+                if (sp < STACK) stk[sp * 256] = (uint32_t)farc;  // host guarantees STACK >= tree depth
+                ++sp;
+            } else if (hL) {
+                node = left;
+            } else if (hR) {
+                node = right;
+            } else if (sp > 0) {
+                --sp;
+                node = (sp < STACK) ? (int)stk[sp * 256] : -1;
+            } else {
+                node = NODE_DONE;
+            }
+            if (node < 0 && leaf == LEAF_NONE) {  // first leaf: postpone it, keep walking
+                leaf = node;
+                if (sp > 0) {
+                    --sp;
+                    node = (sp < STACK) ? (int)stk[sp * 256] : -1;
+                } else {
+                    node = NODE_DONE;
+                }
+            }
+            if (__ballot(leaf == LEAF_NONE && node != NODE_DONE) == 0ull) break;  // nobody is still searching
+        }
+        // ---- phase 2: leaves ----
+        while (leaf != LEAF_NONE) {
+            const uint32_t ref = ~(uint32_t)leaf;
+            const uint32_t first = ref >> 4, cnt = ref & 15u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t slot = first + t;
+                const float4 a = sc.tris[3 * (size_t)slot + 0];
+                const float4 b = sc.tris[3 * (size_t)slot + 1];
+                const float4 c = sc.tris[3 * (size_t)slot + 2];
+                if (STATS) ++n_tris;
+                f3 pos;
+                float b1, b2;
+                if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, ld, pos, b1, b2)) {
+                    const float d2 = dist2(o, pos);
+                    const uint32_t prim = __float_as_uint(a.w);
+                    if (d2 < best.d2 || (d2 == best.d2 && best.id != HIT_MISS && prim < best.prim)) {
+                        best.d2 = d2;
+                        best.id = sc.n_prims + slot;
+                        best.prim = prim;
+                        tlimit = limit_from_d2(d2, pad);
+                    }
+                }
+            }
+            leaf = LEAF_NONE;
+            if (node < 0) {  // the walk stopped on a second leaf: take it now
+                leaf = node;
+                if (sp > 0) {
+                    --sp;
+                    node = (sp < STACK) ? (int)stk[sp * 256] : -1;
+                } else {
+                    node = NODE_DONE;
+                }
+            }
+        }
+    }
+}
+
+template <int STACK, bool STATS, int VARIANT>
+PRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
+                      uint32_t& n_tris) {
+    if (VARIANT == 1)
+        traverse_ifif<STACK, STATS>(sc, o, d, best, stk, n_nodes, n_tris);
+    else
+        traverse_ww<STACK, STATS>(sc, o, d, best, stk, n_nodes, n_tris);
+}
+
+template <int STACK, bool STATS, int VARIANT>
 __global__ void __launch_bounds__(256) k_intersect(DevScene sc, const float4* __restrict__ ro,
                                                    const float4* __restrict__ rd, uint32_t* __restrict__ hit,
                                                    const uint32_t* __restrict__ count_ptr,
@@ -214,7 +335,7 @@ __global__ void __launch_bounds__(256) k_intersect(DevScene sc, const float4* __
             best.id = HIT_MISS;
             best.prim = 0xFFFFFFFFu;
             scan_analytic(sc, o, d, best, n_ptests);
-            if (sc.n_nodes) traverse<STACK, STATS>(sc, o, d, best, &s_stack[threadIdx.x], n_nodes, n_tris);
+            if (sc.n_nodes) traverse<STACK, STATS, VARIANT>(sc, o, d, best, &s_stack[threadIdx.x], n_nodes, n_tris);
             hit[k] = best.id;
         }
     }
@@ -226,20 +347,260 @@ __global__ void __launch_bounds__(256) k_intersect(DevScene sc, const float4* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Default closest-hit pipeline (variant 0): k_scan_prims (coherent linear scan over the analytic primitives,
+// one thread per ray) followed by k_traverse_persistent over the triangles' BVH.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scan_prims(DevScene sc, const float4* __restrict__ ro,
+                                                    const float4* __restrict__ rd, uint32_t* __restrict__ hit,
+                                                    float* __restrict__ hd2, const uint32_t* __restrict__ count_ptr,
+                                                    uint32_t* __restrict__ work,
+                                                    unsigned long long* __restrict__ stats) {
+    const uint32_t count = *count_ptr;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k == 0) work[0] = 0u;  // chunk cursor of the traversal kernel that follows on the stream (work[1]: watchdog flag)
+    if (k >= count) return;
+    const float4 O = ro[k];
+    const float4 D = rd[k];
+    Closest best;
+    best.d2 = 3.402823466e+38f;  // FLT_MAX (primitive.cpp:23)
+    best.id = HIT_MISS;
+    best.prim = 0xFFFFFFFFu;
+    uint32_t n_ptests = 0;
+    if (D.x == 0.0f && D.y == 0.0f && D.z == 0.0f) {
+        best.id = HIT_DEAD;
+    } else {
+        scan_analytic(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), best, n_ptests);
+    }
+    hit[k] = best.id;
+    hd2[k] = best.d2;
+    if (stats) atomicAdd(&stats[2], (unsigned long long)n_ptests);
+}
+
+// Persistent-wavefront traversal with ray replacement.  A fixed grid of waves stays resident; every wave
+// grabs chunks of the bounce's ray buffer with one global atomic per `chunk` rays (a single counter word only
+// sustains ~88 returning atomics/us, so rays are never fetched one wave-load at a time) and hands the rays
+// to its lanes.  A lane whose ray is finished writes its hit id and goes idle; when at least tune.refill_min
+// lanes of the wave are idle they are re-filled together, so the 64 lanes stay busy although incoherent rays
+// need very different numbers of steps.  Traversal is the speculative while-while of traverse_ww; the per-lane
+// stack keeps its first STACK_L entries in LDS ([entry][lane]: bank = lane, conflict-free) and spills deeper
+// entries to a global buffer ([entry][thread], coalesced).
+template <int STACK_L, bool SPILL>
+struct LaneStack {
+    uint32_t* lds;      // &s_stack[threadIdx.x], stride 256
+    uint32_t* spill;    // &spill[global thread], stride n_threads (SPILL only)
+    uint32_t stride;
+    int sp;
+    PRT_DEV void push(uint32_t v) {
+        if (!SPILL || sp < STACK_L)
+            lds[sp * 256] = v;
+        else
+            spill[(size_t)(sp - STACK_L) * stride] = v;
+        ++sp;
+    }
+    // precondition: sp > 0
+    PRT_DEV int pop() {
+        --sp;
+        if (!SPILL || sp < STACK_L) return (int)lds[sp * 256];
+        return (int)spill[(size_t)(sp - STACK_L) * stride];
+    }
+};
+
+template <int STACK_L, int WAVES, bool SPILL, bool STATS>
+__global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc, const float4* __restrict__ ro,
+                                                                    const float4* __restrict__ rd,
+                                                                    uint32_t* __restrict__ hit,
+                                                                    const float* __restrict__ hd2,
+                                                                    const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ work,
+                                                                    uint32_t* __restrict__ spill, PrtTravTuning tune,
+                                                                    unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t s_stack[STACK_L * 256];
+    __shared__ uint32_t s_iters[4];
+    const uint32_t count = *count_ptr;
+    const uint32_t chunk = tune.chunk;
+    if (STATS) {
+        if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    LaneStack<STACK_L, SPILL> st;
+    st.lds = &s_stack[threadIdx.x];
+    st.stride = gridDim.x * 256u;
+    st.spill = spill + (blockIdx.x * 256u + threadIdx.x);
+    st.sp = 0;
+    const uint32_t lane = lane_id();
+    uint32_t k = 0xFFFFFFFFu;
+    int node = NODE_DONE, leaf = LEAF_NONE;
+    f3 o = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f, pad = 0.f, tlimit = 0.f;
+    Closest best;
+    best.d2 = 3.402823466e+38f;
+    best.id = HIT_MISS;
+    best.prim = 0xFFFFFFFFu;
+    uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
+    bool exhausted = false;         // wave-uniform
+    // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
+    // idle; the iteration cap is a watchdog (a wave handles ~count/waves rays x ~100 steps, orders of magnitude
+    // below it) that turns a would-be hang into an error flag the host reports.
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > (1u << 22)) {
+            if (lane == 0) atomicOr(work + 1, 1u);
+            break;
+        }
+        const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
+        if (idle && k != 0xFFFFFFFFu) {
+            hit[k] = best.id;
+            k = 0xFFFFFFFFu;
+        }
+        const unsigned long long idle_mask = __ballot(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (!exhausted && n_idle >= tune.refill_min) {
+            if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(work, 1u);
+                c = (uint32_t)__shfl((int)c, 0, 64);
+                const unsigned long long b64 = (unsigned long long)c * chunk;
+                if (b64 >= count) {
+                    exhausted = true;
+                } else {
+                    cur = (uint32_t)b64;
+                    cur_end = (cur + chunk < count) ? cur + chunk : count;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t kk = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && kk < cur_end) {
+                    const uint32_t hid = hit[kk];
+                    if (hid != HIT_DEAD) {
+                        const float4 O = ro[kk];
+                        const float4 D = rd[kk];
+                        o = mk3(O.x, O.y, O.z);
+                        ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
+                        pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        ax = (o.x + pad) * ix; ay = (o.y + pad) * iy; az = (o.z + pad) * iz;
+                        bx = (o.x - pad) * ix; by = (o.y - pad) * iy; bz = (o.z - pad) * iz;
+                        best.id = hid;
+                        best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
+                        best.d2 = hd2[kk];
+                        tlimit = limit_from_d2(best.d2, pad);
+                        k = kk;
+                        node = 0;
+                        leaf = LEAF_NONE;
+                        st.sp = 0;
+                    }
+                }
+                cur = (cur + n_idle < cur_end) ? cur + n_idle : cur_end;
+            }
+        }
+        if (__ballot(k != 0xFFFFFFFFu) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- phase 1: internal nodes (leave when at most exit_max lanes are still looking for a leaf) ----
+        while ((unsigned)node < 0x40000000u) {
+            const float4 q0 = sc.nodes[4 * (size_t)node + 0];
+            const float4 q1 = sc.nodes[4 * (size_t)node + 1];
+            const float4 q2 = sc.nodes[4 * (size_t)node + 2];
+            const float4 q3 = sc.nodes[4 * (size_t)node + 3];
+            if (STATS) {
+                ++n_nodes;
+                if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[threadIdx.x >> 6];
+            }
+            const float l0x = __builtin_fmaf(q0.x, ix, -ax), l1x = __builtin_fmaf(q0.w, ix, -bx);
+            const float l0y = __builtin_fmaf(q0.y, iy, -ay), l1y = __builtin_fmaf(q1.x, iy, -by);
+            const float l0z = __builtin_fmaf(q0.z, iz, -az), l1z = __builtin_fmaf(q1.y, iz, -bz);
+            const float r0x = __builtin_fmaf(q1.z, ix, -ax), r1x = __builtin_fmaf(q2.y, ix, -bx);
+            const float r0y = __builtin_fmaf(q1.w, iy, -ay), r1y = __builtin_fmaf(q2.z, iy, -by);
+            const float r0z = __builtin_fmaf(q2.x, iz, -az), r1z = __builtin_fmaf(q2.w, iz, -bz);
+            const float tnL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l0x, l1x), __builtin_fminf(l0y, l1y)),
+                                              __builtin_fmaxf(__builtin_fminf(l0z, l1z), 0.0f));
+            const float tfL = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l0x, l1x), __builtin_fmaxf(l0y, l1y)),
+                                              __builtin_fminf(__builtin_fmaxf(l0z, l1z), tlimit));
+            const float tnR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r0x, r1x), __builtin_fminf(r0y, r1y)),
+                                              __builtin_fmaxf(__builtin_fminf(r0z, r1z), 0.0f));
+            const float tfR = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r0x, r1x), __builtin_fmaxf(r0y, r1y)),
+                                              __builtin_fminf(__builtin_fmaxf(r0z, r1z), tlimit));
+            const bool hL = tnL <= tfL * 1.0000005f;
+            const bool hR = tnR <= tfR * 1.0000005f;
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            // select chain instead of a 4-way branch: candidate = nearer hit child, or NEED_POP
+            const bool both = hL && hR;
+            const bool lfirst = tnL <= tnR;
+            const int nearc = lfirst ? left : right;
+            const int farc = lfirst ? right : left;
+            const int cand = both ? nearc : (hL ? left : (hR ? right : NEED_POP));
+            if (both) st.push((uint32_t)farc);
+            node = cand;
+            if (cand == NEED_POP) node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            if (node < 0 && leaf == LEAF_NONE) {  // first leaf (a child or a popped entry): postpone it, keep walking
+                leaf = node;
+                node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            }
+            if ((uint32_t)__popcll(__ballot(leaf == LEAF_NONE && node != NODE_DONE)) <= tune.exit_max) break;
+        }
+        // ---- phase 2: leaves ----
+        while (leaf != LEAF_NONE) {
+            const uint32_t ref = ~(uint32_t)leaf;
+            const uint32_t first = ref >> 4, cnt = ref & 15u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t slot = first + t;
+                const float4 a = sc.tris[3 * (size_t)slot + 0];
+                const float4 b = sc.tris[3 * (size_t)slot + 1];
+                const float4 c = sc.tris[3 * (size_t)slot + 2];
+                if (STATS) ++n_tris;
+                f3 pos;
+                float b1, b2;
+                if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, ld, pos, b1, b2)) {
+                    const float d2 = dist2(o, pos);
+                    const uint32_t prim = __float_as_uint(a.w);
+                    if (d2 < best.d2 || (d2 == best.d2 && best.id != HIT_MISS && prim < best.prim)) {
+                        best.d2 = d2;
+                        best.id = sc.n_prims + slot;
+                        best.prim = prim;
+                        tlimit = limit_from_d2(d2, pad);
+                    }
+                }
+            }
+            leaf = LEAF_NONE;
+            if (node < 0) {  // the walk stopped on a second leaf: take it now
+                leaf = node;
+                node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        __syncthreads();
+        if (threadIdx.x < 4) atomicAdd(&stats[3], 64ull * s_iters[threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Shade + scatter + compaction (ShadeHitsKernel, renderer.cu:274-335; the miss branch of
 // IntersectClosestKernel, renderer.cu:263-271; path logic of TraceRayGPU, cuda_megakernel/renderer.cu:81-119).
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_shade(DevScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd,
-                                               const float4* __restrict__ rt, const uint32_t* __restrict__ hit,
-                                               float4* __restrict__ no, float4* __restrict__ nd,
-                                               float4* __restrict__ nt, float4* __restrict__ rad,
-                                               uint32_t* __restrict__ counts, uint32_t depth, uint32_t max_depth) {
+// Compaction: the survivors of a 1024-thread block reserve their slots in the next bounce's buffer with ONE
+// atomic (wave ballots -> LDS -> thread 0).  A single counter word sustains only ~88 returning atomics/us
+// (MI355X_MICROARCH.md "dequeue"), so the per-wave form (the wave64 equivalent of the reference's
+// warp-aggregated AllocateSlot, renderer.cu:43-67) costs ~0.9 ms per 8 M rays; per-block it is 16x fewer.
+#define SHADE_BLOCK 1024
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
+                                                      const float4* __restrict__ rd, const float4* __restrict__ rt,
+                                                      const uint32_t* __restrict__ hit, float4* __restrict__ no,
+                                                      float4* __restrict__ nd, float4* __restrict__ nt,
+                                                      float4* __restrict__ rad, uint32_t* __restrict__ counts,
+                                                      uint32_t depth, uint32_t max_depth) {
+    __shared__ uint32_t s_cnt[SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base;
     const uint32_t count = counts[depth];
-    const uint32_t wave_base = (blockIdx.x * 256u + threadIdx.x) & ~63u;
-    if (wave_base >= count) return;  // whole wave exits together
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // whole block exits together
+    const uint32_t k = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
     bool want = false;
     float4 O2, D2, T2;
     if (k < count) {
@@ -281,8 +642,20 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, const float4* __rest
             }
         }
     }
-    const uint32_t slot = wave_alloc(&counts[depth + 1u], want);
+    const unsigned long long mask = __ballot(want);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < SHADE_BLOCK / 64; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(&counts[depth + 1u], total) : 0u;
+    }
+    __syncthreads();
     if (want) {
+        uint32_t slot = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) slot += s_cnt[w];
         no[slot] = O2;
         nd[slot] = D2;
         nt[slot] = T2;
@@ -460,29 +833,61 @@ void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& t
                        out.o, out.d, out.t, rad, counts, max_depth);
 }
 
+void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, float* hd2,
+                           const uint32_t* count_ptr, uint32_t* work, uint32_t max_rays, unsigned long long* stats) {
+    hipLaunchKernelGGL(k_scan_prims, dim3(blocks_for(max_rays)), dim3(256), 0, st, sc, in.o, in.d, hit, hd2, count_ptr,
+                       work, stats);
+}
+
+void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
+                         const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
+                         uint32_t tree_depth, const PrtTravTuning& tune, unsigned long long* stats) {
+    uint32_t g = tune.grid_blocks;
+    const uint32_t need = blocks_for(max_rays);
+    if (g > need) g = need;
+    if (g == 0) g = 1;
+    const dim3 grid(g), block(256);
+#define PRT_LAUNCH_T(L, W, SP)                                                                                        \
+    do {                                                                                                              \
+        if (stats)                                                                                                    \
+            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, hit, hd2,  \
+                               count_ptr, work, spill, tune, stats);                                                  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, hit, hd2, \
+                               count_ptr, work, spill, tune, stats);                                                  \
+    } while (0)
+    // tree_depth <= stack entries in LDS: no spill code at all; deeper trees keep 31 entries in LDS + global spill
+    // a root-to-leaf path with tree_depth levels has tree_depth - 1 internal nodes = at most that many pushes
+    const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;
+    if (pushes <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(24, 6, false);
+    else if (pushes <= 31) PRT_LAUNCH_T(31, 5, false);
+    else PRT_LAUNCH_T(31, 5, true);
+#undef PRT_LAUNCH_T
+}
+
+// Variants 1 (while-while) and 2 (one-loop): the fused one-thread-per-ray kernel, kept for A/B runs.
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
                           const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
                           unsigned long long* stats) {
     const dim3 grid(blocks_for(max_rays)), block(256);
-    (void)variant;
+#define PRT_LAUNCH_I(S, T, V) \
+    hipLaunchKernelGGL((k_intersect<S, T, V>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats)
+    const bool deep = stack_depth > 31;
     if (stats) {
-        if (stack_depth <= 32)
-            hipLaunchKernelGGL((k_intersect<32, true>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
-        else
-            hipLaunchKernelGGL((k_intersect<64, true>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+        if (variant == 2) { if (deep) PRT_LAUNCH_I(63, true, 1); else PRT_LAUNCH_I(31, true, 1); }
+        else              { if (deep) PRT_LAUNCH_I(63, true, 0); else PRT_LAUNCH_I(31, true, 0); }
     } else {
-        if (stack_depth <= 32)
-            hipLaunchKernelGGL((k_intersect<32, false>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
-        else
-            hipLaunchKernelGGL((k_intersect<64, false>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats);
+        if (variant == 2) { if (deep) PRT_LAUNCH_I(63, false, 1); else PRT_LAUNCH_I(31, false, 1); }
+        else              { if (deep) PRT_LAUNCH_I(63, false, 0); else PRT_LAUNCH_I(31, false, 0); }
     }
+#undef PRT_LAUNCH_I
 }
 
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* hit,
                       const PrtRayBuf& out, float4* rad, uint32_t* counts, uint32_t depth, uint32_t max_depth,
                       uint32_t max_rays) {
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_rays)), dim3(256), 0, st, sc, in.o, in.d, in.t, hit, out.o, out.d,
-                       out.t, rad, counts, depth, max_depth);
+    hipLaunchKernelGGL(k_shade, dim3((uint32_t)((max_rays + SHADE_BLOCK - 1) / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc,
+                       in.o, in.d, in.t, hit, out.o, out.d, out.t, rad, counts, depth, max_depth);
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,

@@ -326,6 +326,9 @@ class HipWavefrontRenderer:
     def set_variant(self, v: int):
         self._check(capi.lib().prt_set_variant(self._ctx, v))
 
+    def set_param(self, name: str, value: int):
+        self._check(capi.lib().prt_set_param(self._ctx, name.encode(), int(value)))
+
     def download(self) -> Film:
         f = self.film
         self._check(capi.lib().prt_film_read(self._ctx, f.accum.ctypes.data_as(_fp), f.weights.ctypes.data_as(_fp)))
