@@ -26,10 +26,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-NODE_BYTES = 64        # one BVH2 node visit: two child AABBs + two child refs (csrc/bvh.h)
+NODE_BYTES = 128       # one BVH4 node visit: four child AABBs + four child refs = one cache line (csrc/bvh.h)
 TRI_BYTES = 48         # one leaf triangle test: 3 x float4 (P0+prim, P1+material, P2)
 RAY_FIXED_BYTES = 36   # k_intersect per ray: origin+dir read (2 x 16 B) + hit id write (4 B)
 PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
+
+
+def load_traffic(config, world, spp_step, sif):
+    import glob
+    best = (None, "no committed PMC profile matches this configuration")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if (t.get("config"), t.get("n_gpus"), t.get("spp_per_step"), t.get("samples_in_flight")) == (config, world, spp_step, sif):
+            best = (t.get("hbm_bytes_per_launch"), f"{os.path.basename(f)}: {t.get('note', '')}")
+    return best
 
 
 def parse():
@@ -142,8 +155,12 @@ def main():
         # sample; a launch is one depth of one batch of `sif` samples: bytes/launch = total bytes / launches
         bytes_per_launch = alg_bytes_sample * st.samples / st.intersect_launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # measured HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
+        # (profiles/*_traffic.json, written by tools/pmc_traffic.py); null when no matching profile is committed
+        traffic, traffic_note = load_traffic(args.config, world, spp_step, sif)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_intersect",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                    "kernel": "k_traverse4_persistent",
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
                     "alg_bytes_per_launch": int(bytes_per_launch),
                     "node_visits_per_ray": round(trav.bvh_node_visits / max(1, rays_sample), 2),

@@ -144,8 +144,10 @@ typedef struct PrtBvhInfo {
     uint32_t max_leaf_size;
     float sah_cost;
     float pad_abs;     /* absolute AABB padding applied (conservative culling) */
-    uint64_t node_bytes;
+    uint64_t node_bytes;   /* bytes of the 4-wide tree the default kernel walks */
     uint64_t tri_bytes;
+    uint32_t n_nodes4;     /* 4-wide nodes (128 B each) */
+    uint32_t max_stack4;   /* worst-case traversal stack entries of the 4-wide tree */
 } PrtBvhInfo;
 
 typedef struct PrtContext PrtContext;
@@ -218,9 +220,11 @@ int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
 /* Copies the built BVH out (host arrays): nodes n_nodes*16 floats (layout: csrc/bvh.h), tris
  * n_triangles*12 floats in leaf order.  Either pointer may be NULL.  Works on host-only contexts. */
 int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);
+/* The 4-wide tree: n_nodes4*32 floats (layout: csrc/bvh.h). */
+int prt_bvh_read4(PrtContext* ctx, float* nodes4);
 /* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
 int prt_set_variant(PrtContext* ctx, int variant);
-/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "stack_lds". */
+/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "wide", "stack_lds". */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */

@@ -2,17 +2,21 @@
 #include "bvh.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <thread>
 
 namespace {
 
 constexpr int kBins = 16;
 constexpr float kTraversalCost = 1.0f;
-constexpr float kIntersectCost = 1.5f;
+// SAH cost of one triangle test relative to one node visit; PRT_BVH_CI overrides it for tuning runs
+static float kIntersectCost = 1.5f;
 
 struct Box {
     float mn[3], mx[3];
@@ -185,11 +189,15 @@ struct Builder {
 bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int n_threads, uint32_t max_allowed_depth,
                BvhBuild* out) {
     out->nodes.clear();
+    out->nodes4.clear();
+    out->max_stack4 = 0;
     out->order.clear();
     out->max_depth = 0;
     out->max_leaf = 0;
     out->sah_cost = 0.0f;
     if (n_tris == 0) return true;
+    if (const char* e = getenv("PRT_BVH_CI")) kIntersectCost = (float)atof(e);
+    if (const char* e = getenv("PRT_BVH_MAXLEAF")) max_leaf_size = (uint32_t)atoi(e);
     if (max_leaf_size < 1) max_leaf_size = 1;
     if (max_leaf_size > 15) max_leaf_size = 15;
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -348,6 +356,93 @@ bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int 
         }
     }
     out->sah_cost = (float)sah;
+
+    // ---- BVH4: collapse the binary tree (the child with the largest area is replaced by its two children
+    // until a node has four children or only leaves are left).  128 B per node, see bvh.h. ----
+    {
+        struct Item4 {
+            uint32_t build;  // build node whose (collapsed) children form this wide node
+            uint32_t dev;
+        };
+        const float kInf = std::numeric_limits<float>::infinity();
+        out->nodes4.clear();
+        auto collapse = [&](uint32_t ni, uint32_t* kids) -> int {
+            int n = 0;
+            if (is_leaf(ni)) {
+                kids[n++] = ni;
+                return n;
+            }
+            kids[n++] = (uint32_t)b.nodes[ni].left;
+            kids[n++] = (uint32_t)b.nodes[ni].right;
+            while (n < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (int k = 0; k < n; ++k)
+                    if (!is_leaf(kids[k])) {
+                        const float a = b.nodes[kids[k]].box.half_area();
+                        if (a > best) {
+                            best = a;
+                            pick = k;
+                        }
+                    }
+                if (pick < 0) break;
+                const uint32_t c = kids[pick];
+                kids[pick] = (uint32_t)b.nodes[c].left;
+                kids[n++] = (uint32_t)b.nodes[c].right;
+            }
+            return n;
+        };
+        std::vector<Item4> st;
+        std::vector<uint32_t> need;  // per wide node: worst-case pushes below it (filled bottom-up afterwards)
+        std::vector<std::array<int32_t, 4>> refs;
+        st.push_back({0, 0});
+        out->nodes4.assign(32, 0.0f);
+        refs.push_back({-1, -1, -1, -1});
+        while (!st.empty()) {
+            const Item4 it = st.back();
+            st.pop_back();
+            uint32_t kids[4];
+            const int n = collapse(it.build, kids);
+            float* q = &out->nodes4[32 * (size_t)it.dev];
+            std::array<int32_t, 4> r{-1, -1, -1, -1};
+            for (int c = 0; c < 4; ++c) {
+                if (c < n) {
+                    const Box& bx = b.nodes[kids[c]].box;
+                    q[0 + c] = bx.mn[0]; q[4 + c] = bx.mx[0];
+                    q[8 + c] = bx.mn[1]; q[12 + c] = bx.mx[1];
+                    q[16 + c] = bx.mn[2]; q[20 + c] = bx.mx[2];
+                    if (is_leaf(kids[c])) {
+                        r[c] = leaf_ref(kids[c]);
+                    } else {
+                        const uint32_t dev = (uint32_t)(out->nodes4.size() / 32);
+                        out->nodes4.resize(out->nodes4.size() + 32, 0.0f);
+                        q = &out->nodes4[32 * (size_t)it.dev];  // resize may have moved the storage
+                        refs.push_back({-1, -1, -1, -1});
+                        r[c] = (int32_t)dev;
+                        st.push_back({kids[c], dev});
+                    }
+                } else {  // empty child: a box no ray can enter, empty leaf
+                    q[0 + c] = q[4 + c] = q[8 + c] = q[12 + c] = q[16 + c] = q[20 + c] = kInf;
+                    r[c] = ~0;
+                }
+            }
+            memcpy(&q[24], r.data(), 16);
+            refs[it.dev] = r;
+        }
+        // worst-case stack need: a node with m children pushes at most m-1 refs, then one child is entered
+        const size_t n4 = refs.size();
+        need.assign(n4, 0);
+        for (size_t i = n4; i-- > 0;) {  // children always have larger indices than their parent
+            uint32_t m = 0, deepest = 0;
+            for (int c = 0; c < 4; ++c) {
+                if (refs[i][c] == ~0) continue;
+                ++m;
+                if (refs[i][c] >= 0) deepest = std::max(deepest, need[(size_t)refs[i][c]]);
+            }
+            need[i] = (m ? m - 1 : 0) + deepest;
+        }
+        out->max_stack4 = need[0];
+    }
     out->order = std::move(b.order);
     return out->max_depth <= max_allowed_depth;
 }

@@ -10,13 +10,20 @@
 //   q2 = (Rmin.z, Rmax.x, Rmax.y, Rmax.z)   q3 = (left, right, 0, 0) as int bits
 // child ref >= 0: internal node index; < 0: leaf, ~ref = (first_triangle_slot << 4) | count (count 0..15).
 // Boxes are the exact fp32 bounds of the vertices (padding is applied per ray by the kernel).
+//
+// Wide node (BVH4, what the default traversal kernel walks) = 128 B = 8 x float4, one cache line:
+//   q0 = min.x of children 0..3   q1 = max.x   q2 = min.y   q3 = max.y   q4 = min.z   q5 = max.z
+//   q6 = child refs 0..3 (same encoding)       q7 = unused
+// built by collapsing the binary tree; an absent child has an all-+inf box and the empty-leaf ref ~0.
 #pragma once
 #include <stdint.h>
 
 #include <vector>
 
 struct BvhBuild {
-    std::vector<float> nodes;     // 16 floats per node
+    std::vector<float> nodes;     // 16 floats per binary node
+    std::vector<float> nodes4;    // 32 floats per wide node
+    uint32_t max_stack4 = 0;      // worst-case number of stacked refs when walking the wide tree
     std::vector<uint32_t> order;  // leaf slot -> input triangle index
     uint32_t max_depth = 0;       // edges on the longest root-to-leaf path (+1 for the root node itself)
     uint32_t max_leaf = 0;

@@ -53,6 +53,7 @@ struct PrtContext {
     void* d_mat_rgbs = nullptr;
     void* d_mat_type = nullptr;
     void* d_nodes = nullptr;
+    void* d_nodes4 = nullptr;
     void* d_tris = nullptr;
     void* d_nrms = nullptr;
 
@@ -88,7 +89,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
-    PrtTravTuning tune{1280u, 256u, 16u, 16u, 31u};  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
+    PrtTravTuning tune{1280u, 256u, 16u, 16u, 0u, 1u, 31u};  // XCD affinity measured 7 % slower on C3 (uneven eighths)  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -172,8 +173,8 @@ int ensure_counters(PrtContext* c) {
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_work, 64));
-    HIPCHECK(c, hipMemset(c->d_work, 0, 64));
+    HIPCHECK(c, hipMalloc((void**)&c->d_work, 2048));
+    HIPCHECK(c, hipMemset(c->d_work, 0, 2048));
     return PRT_OK;
 }
 
@@ -202,6 +203,7 @@ void free_scene(PrtContext* c) {
     free_dev(c->d_mat_rgbs);
     free_dev(c->d_mat_type);
     free_dev(c->d_nodes);
+    free_dev(c->d_nodes4);
     free_dev(c->d_tris);
     free_dev(c->d_nrms);
     c->has_scene = false;
@@ -284,7 +286,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             if (c->dsc.n_nodes) {
                 if ((rc = begin_event(c, 1, &ep))) return rc;
                 prt_launch_traverse(c->stream, c->dsc, in, c->d_hit, c->d_hd2, c->d_counts + d, c->d_work, c->d_spill,
-                                    n_paths, c->bvh.max_depth, c->tune, trav_stats);
+                                    n_paths, c->bvh.max_depth, c->bvh.max_stack4, c->tune, trav_stats);
                 if ((rc = end_event(c, &ep))) return rc;
             }
         } else {
@@ -459,7 +461,9 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.max_leaf_size = c->bvh.max_leaf;
     bi.sah_cost = c->bvh.sah_cost;
     bi.pad_abs = kPadCoeff;
-    bi.node_bytes = (uint64_t)c->bvh.nodes.size() * 4;
+    bi.node_bytes = (uint64_t)c->bvh.nodes4.size() * 4;
+    bi.n_nodes4 = (uint32_t)(c->bvh.nodes4.size() / 32);
+    bi.max_stack4 = c->bvh.max_stack4;
     bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
 
     DevScene& d = c->dsc;
@@ -497,12 +501,14 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
     HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
     HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
+    HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
     HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
     HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
     d.prims = (const DevPrim*)c->d_prims;
     d.mat_rgbs = (const float4*)c->d_mat_rgbs;
     d.mat_type = (const uint32_t*)c->d_mat_type;
     d.nodes = (const float4*)c->d_nodes;
+    d.nodes4 = (const float4*)c->d_nodes4;
     d.tris = (const float4*)c->d_tris;
     d.tri_normals = (const float4*)c->d_nrms;
     return ensure_counters(c);
@@ -593,10 +599,10 @@ int prt_synchronize(PrtContext* c) {
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_work) {  // watchdog flag of the persistent traversal kernel
-        uint32_t w[2] = {0, 0};
-        HIPCHECK(c, hipMemcpy(w, c->d_work, sizeof(w), hipMemcpyDeviceToHost));
-        if (w[1]) {
-            HIPCHECK(c, hipMemset(c->d_work, 0, 64));
+        uint32_t w = 0;
+        HIPCHECK(c, hipMemcpy(&w, c->d_work + 256, sizeof(w), hipMemcpyDeviceToHost));
+        if (w) {
+            HIPCHECK(c, hipMemset(c->d_work, 0, 2048));
             return fail(c, PRT_ERR_HIP, "traversal watchdog tripped: a wave exceeded its iteration cap");
         }
     }
@@ -738,7 +744,7 @@ int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float
         if ((rc = ensure_spill(c))) return rc;
         prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, n, nullptr);
         if (c->dsc.n_nodes)
-            prt_launch_traverse(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, c->d_spill, n, c->bvh.max_depth, c->tune, nullptr);
+            prt_launch_traverse(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, c->d_spill, n, c->bvh.max_depth, c->bvh.max_stack4, c->tune, nullptr);
     } else {
         prt_launch_intersect(c->stream, c->dsc, c->rb[0], c->d_hit, cnt, n, stack_depth, c->variant, nullptr);
     }
@@ -873,6 +879,13 @@ int prt_bvh_info(PrtContext* c, PrtBvhInfo* out) {
     return PRT_OK;
 }
 
+int prt_bvh_read4(PrtContext* c, float* nodes4) {
+    if (!c) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (nodes4) memcpy(nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4);
+    return PRT_OK;
+}
+
 int prt_bvh_read(PrtContext* c, float* nodes, float* tris) {
     if (!c) return PRT_ERR_INVALID;
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
@@ -887,7 +900,9 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     if (n == "variant") c->variant = value;
     else if (n == "grid_blocks" && value > 0 && value <= 8192) c->tune.grid_blocks = (uint32_t)value;
     else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
-    else if (n == "stack_lds" && (value == 24 || value == 31)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
+    else if (n == "wide" && (value == 0 || value == 1)) c->tune.wide = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 24 || value == 31 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
     else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;
     else return fail(c, PRT_ERR_INVALID, "unknown parameter or bad value: %s = %d", name, value);

@@ -29,6 +29,7 @@ struct DevScene {
     const float4* mat_rgbs;     // rgb + scalar
     const uint32_t* mat_type;
     const float4* nodes;        // 4 x float4 per BVH2 node (see bvh.h)
+    const float4* nodes4;       // 8 x float4 per BVH4 node (see bvh.h)
     const float4* tris;         // 3 x float4 per triangle, leaf order: {P0, prim}, {P1, material}, {P2, 0}
     const float4* tri_normals;  // 3 x float4 per triangle, leaf order
     uint32_t n_prims;
@@ -52,6 +53,8 @@ struct PrtTravTuning {
     uint32_t chunk;        // rays a wave grabs per global atomic (multiple of 64)
     uint32_t refill_min;   // idle lanes of a wave that trigger a refill
     uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf
+    uint32_t xcd_affinity; // 1: each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
+    uint32_t wide;         // 1: walk the 4-wide tree (default), 0: the binary tree
     uint32_t stack_lds;    // per-lane stack entries kept in LDS: 31 (5 blocks/CU) or 24 (6 blocks/CU, trees of depth <= 24)
 };
 
@@ -68,7 +71,7 @@ void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& 
                            const uint32_t* count_ptr, uint32_t* work, uint32_t max_rays, unsigned long long* stats);
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
                          const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
-                         uint32_t tree_depth, const PrtTravTuning& tune, unsigned long long* stats);
+                         uint32_t tree_depth, uint32_t stack4, const PrtTravTuning& tune, unsigned long long* stats);
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
                           const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
                           unsigned long long* stats);

@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_scan_prims(DevScene sc, const float4* _
                                                     unsigned long long* __restrict__ stats) {
     const uint32_t count = *count_ptr;
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k == 0) work[0] = 0u;  // chunk cursor of the traversal kernel that follows on the stream (work[1]: watchdog flag)
+    if (k < 8u) work[32u * k] = 0u;  // chunk cursors of the traversal kernel that follows on the stream (work[256]: watchdog flag)
     if (k >= count) return;
     const float4 O = ro[k];
     const float4 D = rd[k];
@@ -384,6 +384,29 @@ __global__ void __launch_bounds__(256) k_scan_prims(DevScene sc, const float4* _
 // need very different numbers of steps.  Traversal is the speculative while-while of traverse_ww; the per-lane
 // stack keeps its first STACK_L entries in LDS ([entry][lane]: bank = lane, conflict-free) and spills deeper
 // entries to a global buffer ([entry][thread], coalesced).
+// XCD id of the executing wave (HW_REG_XCC_ID, bits 3:0).  Used for L2 affinity only, never for correctness.
+PRT_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 7u; }
+
+// Chunk cursor(s) of the persistent traversal kernels: work[32 * x] (own 128-B line each) counts the chunks
+// taken from XCD x's contiguous eighth of the ray buffer.  Neighbouring rays start in neighbouring parts of the
+// scene, so keeping an eighth of the buffer on one XCD keeps the deep BVH levels it touches in that XCD's 4 MB L2.
+// A wave first drains its own XCD's range, then steals from the others, so the grid still balances.
+PRT_DEV uint32_t grab_chunk(uint32_t* work, uint32_t n_chunks, uint32_t my_xcd, bool affinity) {
+    if (!affinity) {
+        const uint32_t c = atomicAdd(work, 1u);
+        return c < n_chunks ? c : 0xFFFFFFFFu;
+    }
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const uint32_t x = (my_xcd + i) & 7u;
+        const uint32_t lo = (uint32_t)(((unsigned long long)n_chunks * x) >> 3);
+        const uint32_t hi = (uint32_t)(((unsigned long long)n_chunks * (x + 1u)) >> 3);
+        if (work[32u * x] >= hi - lo) continue;  // already drained (plain read: a stale value only costs one atomic)
+        const uint32_t c = atomicAdd(&work[32u * x], 1u);
+        if (c < hi - lo) return lo + c;
+    }
+    return 0xFFFFFFFFu;
+}
+
 template <int STACK_L, bool SPILL>
 struct LaneStack {
     uint32_t* lds;      // &s_stack[threadIdx.x], stride 256
@@ -418,6 +441,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
     __shared__ uint32_t s_iters[4];
     const uint32_t count = *count_ptr;
     const uint32_t chunk = tune.chunk;
+    const uint32_t n_chunks = (count + chunk - 1u) / chunk;
+    const uint32_t my_xcd = xcc_id();
     if (STATS) {
         if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
         __syncthreads();
@@ -444,7 +469,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
     // below it) that turns a would-be hang into an error flag the host reports.
     for (uint32_t guard = 0;; ++guard) {
         if (guard > (1u << 22)) {
-            if (lane == 0) atomicOr(work + 1, 1u);
+            if (lane == 0) atomicOr(work + 256, 1u);
             break;
         }
         const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
@@ -456,14 +481,13 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (!exhausted && n_idle >= tune.refill_min) {
             if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(work, 1u);
+                uint32_t c = 0xFFFFFFFFu;
+                if (lane == 0) c = grab_chunk(work, n_chunks, my_xcd, tune.xcd_affinity != 0u);
                 c = (uint32_t)__shfl((int)c, 0, 64);
-                const unsigned long long b64 = (unsigned long long)c * chunk;
-                if (b64 >= count) {
+                if (c == 0xFFFFFFFFu) {
                     exhausted = true;
                 } else {
-                    cur = (uint32_t)b64;
+                    cur = c * chunk;
                     cur_end = (cur + chunk < count) ? cur + chunk : count;
                 }
             }
@@ -535,6 +559,197 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
             if (both) st.push((uint32_t)farc);
             node = cand;
             if (cand == NEED_POP) node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            if (node < 0 && leaf == LEAF_NONE) {  // first leaf (a child or a popped entry): postpone it, keep walking
+                leaf = node;
+                node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            }
+            if ((uint32_t)__popcll(__ballot(leaf == LEAF_NONE && node != NODE_DONE)) <= tune.exit_max) break;
+        }
+        // ---- phase 2: leaves ----
+        while (leaf != LEAF_NONE) {
+            const uint32_t ref = ~(uint32_t)leaf;
+            const uint32_t first = ref >> 4, cnt = ref & 15u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t slot = first + t;
+                const float4 a = sc.tris[3 * (size_t)slot + 0];
+                const float4 b = sc.tris[3 * (size_t)slot + 1];
+                const float4 c = sc.tris[3 * (size_t)slot + 2];
+                if (STATS) ++n_tris;
+                f3 pos;
+                float b1, b2;
+                if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, ld, pos, b1, b2)) {
+                    const float d2 = dist2(o, pos);
+                    const uint32_t prim = __float_as_uint(a.w);
+                    if (d2 < best.d2 || (d2 == best.d2 && best.id != HIT_MISS && prim < best.prim)) {
+                        best.d2 = d2;
+                        best.id = sc.n_prims + slot;
+                        best.prim = prim;
+                        tlimit = limit_from_d2(d2, pad);
+                    }
+                }
+            }
+            leaf = LEAF_NONE;
+            if (node < 0) {  // the walk stopped on a second leaf: take it now
+                leaf = node;
+                node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        __syncthreads();
+        if (threadIdx.x < 4) atomicAdd(&stats[3], 64ull * s_iters[threadIdx.x]);
+    }
+}
+
+// The same kernel over the 4-wide tree (default): half as many dependent node fetches per ray, one 128-B cache
+// line per visit, children visited in entry-distance order (5-comparator sorting network).
+template <int STACK_L, int WAVES, bool SPILL, bool STATS>
+__global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc, const float4* __restrict__ ro,
+                                                                    const float4* __restrict__ rd,
+                                                                    uint32_t* __restrict__ hit,
+                                                                    const float* __restrict__ hd2,
+                                                                    const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ work,
+                                                                    uint32_t* __restrict__ spill, PrtTravTuning tune,
+                                                                    unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t s_stack[STACK_L * 256];
+    __shared__ uint32_t s_iters[4];
+    const uint32_t count = *count_ptr;
+    const uint32_t chunk = tune.chunk;
+    const uint32_t n_chunks = (count + chunk - 1u) / chunk;
+    const uint32_t my_xcd = xcc_id();
+    if (STATS) {
+        if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    LaneStack<STACK_L, SPILL> st;
+    st.lds = &s_stack[threadIdx.x];
+    st.stride = gridDim.x * 256u;
+    st.spill = spill + (blockIdx.x * 256u + threadIdx.x);
+    st.sp = 0;
+    const uint32_t lane = lane_id();
+    uint32_t k = 0xFFFFFFFFu;
+    int node = NODE_DONE, leaf = LEAF_NONE;
+    f3 o = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f, pad = 0.f, tlimit = 0.f;
+    Closest best;
+    best.d2 = 3.402823466e+38f;
+    best.id = HIT_MISS;
+    best.prim = 0xFFFFFFFFu;
+    uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
+    bool exhausted = false;         // wave-uniform
+    // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
+    // idle; the iteration cap is a watchdog (a wave handles ~count/waves rays x ~100 steps, orders of magnitude
+    // below it) that turns a would-be hang into an error flag the host reports.
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > (1u << 22)) {
+            if (lane == 0) atomicOr(work + 256, 1u);
+            break;
+        }
+        const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
+        if (idle && k != 0xFFFFFFFFu) {
+            hit[k] = best.id;
+            k = 0xFFFFFFFFu;
+        }
+        const unsigned long long idle_mask = __ballot(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (!exhausted && n_idle >= tune.refill_min) {
+            if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
+                uint32_t c = 0xFFFFFFFFu;
+                if (lane == 0) c = grab_chunk(work, n_chunks, my_xcd, tune.xcd_affinity != 0u);
+                c = (uint32_t)__shfl((int)c, 0, 64);
+                if (c == 0xFFFFFFFFu) {
+                    exhausted = true;
+                } else {
+                    cur = c * chunk;
+                    cur_end = (cur + chunk < count) ? cur + chunk : count;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t kk = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && kk < cur_end) {
+                    const uint32_t hid = hit[kk];
+                    if (hid != HIT_DEAD) {
+                        const float4 O = ro[kk];
+                        const float4 D = rd[kk];
+                        o = mk3(O.x, O.y, O.z);
+                        ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
+                        pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        ax = (o.x + pad) * ix; ay = (o.y + pad) * iy; az = (o.z + pad) * iz;
+                        bx = (o.x - pad) * ix; by = (o.y - pad) * iy; bz = (o.z - pad) * iz;
+                        best.id = hid;
+                        best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
+                        best.d2 = hd2[kk];
+                        tlimit = limit_from_d2(best.d2, pad);
+                        k = kk;
+                        node = 0;
+                        leaf = LEAF_NONE;
+                        st.sp = 0;
+                    }
+                }
+                cur = (cur + n_idle < cur_end) ? cur + n_idle : cur_end;
+            }
+        }
+        if (__ballot(k != 0xFFFFFFFFu) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- phase 1: internal nodes (leave when at most exit_max lanes are still looking for a leaf) ----
+        while ((unsigned)node < 0x40000000u) {
+            const float4* nb = sc.nodes4 + 8 * (size_t)node;
+            const float4 mnx = nb[0], mxx = nb[1], mny = nb[2], mxy = nb[3], mnz = nb[4], mxz = nb[5], rf = nb[6];
+            if (STATS) {
+                ++n_nodes;
+                if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[threadIdx.x >> 6];
+            }
+            const float kInf = __builtin_inff();
+            float k0, k1, k2, k3;
+#define PRT_CHILD(C, KEY)                                                                                          \
+    {                                                                                                              \
+        const float x0 = __builtin_fmaf(mnx.C, ix, -ax), x1 = __builtin_fmaf(mxx.C, ix, -bx);                      \
+        const float y0 = __builtin_fmaf(mny.C, iy, -ay), y1 = __builtin_fmaf(mxy.C, iy, -by);                      \
+        const float z0 = __builtin_fmaf(mnz.C, iz, -az), z1 = __builtin_fmaf(mxz.C, iz, -bz);                      \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),        \
+                                         __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));                          \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),        \
+                                         __builtin_fminf(__builtin_fmaxf(z0, z1), tlimit));                        \
+        KEY = (tn <= tf * 1.0000005f) ? tn : kInf;                                                                 \
+    }
+            PRT_CHILD(x, k0)
+            PRT_CHILD(y, k1)
+            PRT_CHILD(z, k2)
+            PRT_CHILD(w, k3)
+#undef PRT_CHILD
+            int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+            // sort the four (entry distance, ref) pairs ascending: 5-comparator network; misses (+inf) end up last
+#define PRT_CSWAP(KA, RA, KB, RB)            \
+    {                                        \
+        const bool sw = KB < KA;             \
+        const float kt = sw ? KB : KA;       \
+        KB = sw ? KA : KB;                   \
+        KA = kt;                             \
+        const int rt = sw ? RB : RA;         \
+        RB = sw ? RA : RB;                   \
+        RA = rt;                             \
+    }
+            PRT_CSWAP(k0, r0, k1, r1)
+            PRT_CSWAP(k2, r2, k3, r3)
+            PRT_CSWAP(k0, r0, k2, r2)
+            PRT_CSWAP(k1, r1, k3, r3)
+            PRT_CSWAP(k1, r1, k2, r2)
+#undef PRT_CSWAP
+            // farthest first, so that the nearest pending child is popped first
+            if (k3 < kInf) st.push((uint32_t)r3);
+            if (k2 < kInf) st.push((uint32_t)r2);
+            if (k1 < kInf) st.push((uint32_t)r1);
+            node = (k0 < kInf) ? r0 : NEED_POP;
+            if (node == NEED_POP) node = (st.sp > 0) ? st.pop() : NODE_DONE;
             if (node < 0 && leaf == LEAF_NONE) {  // first leaf (a child or a popped entry): postpone it, keep walking
                 leaf = node;
                 node = (st.sp > 0) ? st.pop() : NODE_DONE;
@@ -841,7 +1056,7 @@ void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& 
 
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
                          const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
-                         uint32_t tree_depth, const PrtTravTuning& tune, unsigned long long* stats) {
+                         uint32_t tree_depth, uint32_t stack4, const PrtTravTuning& tune, unsigned long long* stats) {
     uint32_t g = tune.grid_blocks;
     const uint32_t need = blocks_for(max_rays);
     if (g > need) g = need;
@@ -858,6 +1073,23 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
     } while (0)
     // tree_depth <= stack entries in LDS: no spill code at all; deeper trees keep 31 entries in LDS + global spill
     // a root-to-leaf path with tree_depth levels has tree_depth - 1 internal nodes = at most that many pushes
+    if (tune.wide) {
+#define PRT_LAUNCH_T4(L, W, SP)                                                                                        \
+    do {                                                                                                               \
+        if (stats)                                                                                                     \
+            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, hit, hd2,  \
+                               count_ptr, work, spill, tune, stats);                                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, hit, hd2, \
+                               count_ptr, work, spill, tune, stats);                                                   \
+    } while (0)
+        if (stack4 <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T4(24, 6, false);
+        else if (stack4 <= 31) PRT_LAUNCH_T4(31, 5, false);
+        else if (stack4 <= 39 && tune.stack_lds != 31) PRT_LAUNCH_T4(39, 4, false);  // all-LDS stack, 4 blocks/CU
+        else PRT_LAUNCH_T4(31, 5, true);
+#undef PRT_LAUNCH_T4
+        return;
+    }
     const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;
     if (pushes <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(24, 6, false);
     else if (pushes <= 31) PRT_LAUNCH_T(31, 5, false);

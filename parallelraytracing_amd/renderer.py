@@ -412,6 +412,12 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_bvh_read(self._ctx, nodes.ctypes.data_as(_fp), tris.ctypes.data_as(_fp)))
         return nodes, tris
 
+    def bvh_read4(self) -> np.ndarray:
+        b = self.bvh_info()
+        nodes4 = np.zeros((b.n_nodes4, 32), np.float32)
+        self._check(capi.lib().prt_bvh_read4(self._ctx, nodes4.ctypes.data_as(_fp)))
+        return nodes4
+
     def set_scene_host_only(self, scene: Scene):
         """For host-only contexts (device < 0): build the BVH without a GPU."""
         d = scene.desc()

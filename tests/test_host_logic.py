@@ -255,6 +255,54 @@ def test_bvh_structure(ply, target):
     assert (tris[:, 7].view(np.uint32) == 2).all()  # material id of mesh_scene's body
 
 
+@pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("dragon.ply", 60_000)])
+def test_bvh4_structure(ply, target):
+    """The 4-wide tree the default kernel walks: 128-B nodes, SoA child boxes, refs in q6."""
+    mesh = prt.Mesh(prt.scenes.asset(ply))
+    if target:
+        mesh.refine(target)
+    sc = prt.scenes.mesh_scene(mesh)
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    info = r.bvh_info()
+    n4 = r.bvh_read4()
+    _, tris = r.bvh_read()
+    nt = mesh.n_triangles
+    assert n4.shape == (info.n_nodes4, 32) and info.node_bytes == n4.nbytes
+    refs = n4[:, 24:28].view(np.int32)
+    covered = np.zeros(nt, np.int32)
+    seen = np.zeros(len(n4), np.int32)
+    n_children = []
+    for node in range(len(n4)):
+        m = 0
+        for c in range(4):
+            ref = int(refs[node, c])
+            lo = n4[node, [0 + c, 8 + c, 16 + c]]
+            hi = n4[node, [4 + c, 12 + c, 20 + c]]
+            if ref == -1:  # absent child: +inf box, empty leaf
+                assert np.isinf(lo).all() and np.isinf(hi).all()
+                continue
+            m += 1
+            if ref < 0:
+                u = (~ref) & 0xFFFFFFFF
+                first, cnt = u >> 4, u & 15
+                assert 1 <= cnt <= 4
+                covered[first:first + cnt] += 1
+                P = tris[first:first + cnt].reshape(cnt, 3, 4)[:, :, :3].reshape(-1, 3)
+                assert (P >= lo).all() and (P <= hi).all()
+            else:
+                assert node < ref < len(n4)
+                seen[ref] += 1
+                clo = np.stack([n4[ref, 0:4], n4[ref, 8:12], n4[ref, 16:20]])
+                chi = np.stack([n4[ref, 4:8], n4[ref, 12:16], n4[ref, 20:24]])
+                fin = np.isfinite(clo[0])
+                assert (clo[:, fin].min(axis=1) >= lo).all() and (chi[:, fin].max(axis=1) <= hi).all()
+        n_children.append(m)
+    assert (covered == 1).all() and (seen[1:] == 1).all() and seen[0] == 0
+    assert np.mean(n_children) > 3.0 or len(n4) < 4  # the collapse really fills the nodes
+    assert 0 < info.max_stack4 <= 63 and info.n_nodes4 < info.n_nodes
+
+
 def test_bvh_single_triangle_and_empty_scene():
     r = prt.HipWavefrontRenderer(device=-1)
     one = prt.Mesh(vertices=np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), indices=np.array([[0, 1, 2]], np.uint32))

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py` into profiles/<name>_traffic.json.
+  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> --config C3 --spp-per-step 32 --sif 32
+Unit and correction follow /opt/skills/guides (cdna_hip_programming.md §7, MI355X_MICROARCH.md §HBM):
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, i.e. HALF the bytes of
+wide (16 B/lane) reads, so the read side is doubled; WRITE_SIZE is exact for 16-B/lane stores.  The counters sit
+on the L2's fabric side, so Infinity-Cache hits are INCLUDED: this is "bytes leaving L2", an upper bound on HBM."""
+import argparse
+import collections
+import csv
+import glob
+import json
+
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch_dir")
+ap.add_argument("write_dir")
+ap.add_argument("out")
+ap.add_argument("--config", default="C3")
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--spp-per-step", type=int, default=32)
+ap.add_argument("--sif", type=int, default=32)
+ap.add_argument("--kernel", default="k_traverse4_persistent")
+args = ap.parse_args()
+
+
+def total(d, counter):
+    s, n = 0.0, set()
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if args.kernel in r["Kernel_Name"] and r["Counter_Name"] == counter and "true>" not in r["Kernel_Name"].split("(")[0]:
+                s += float(r["Counter_Value"])
+                n.add(r["Dispatch_Id"])
+    return s, len(n)
+
+
+fetch, n1 = total(args.fetch_dir, "FETCH_SIZE")
+write, n2 = total(args.write_dir, "WRITE_SIZE")
+assert n1 and n1 == n2, (n1, n2)
+per_launch = (2.0 * fetch + write) * 1024.0 / n1
+json.dump({"config": args.config, "n_gpus": args.gpus, "spp_per_step": args.spp_per_step, "samples_in_flight": args.sif,
+           "kernel": args.kernel, "launches": n1, "fetch_size_kib": fetch, "write_size_kib": write,
+           "hbm_bytes_per_launch": int(per_launch),
+           "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches; x2 = gfx950 correction for wide reads; fabric-side "
+                   "counter, includes Infinity-Cache hits"}, open(args.out, "w"), indent=1)
+print(open(args.out).read())
