@@ -7,9 +7,10 @@
 Workload (config.workload): C3 of SURVEY.md §8(d) — the bundled dragon.ply refined by deterministic
 longest-edge bisection to 870,000 triangles, on a ground quad under an emissive quad, 1920x1080,
 max_depth = 5 segments ("4 bounces"), synthetic (there is no 1M-triangle scene in the reference).
-A "step" is one progressive pass of --spp-per-step samples per pixel over the whole frame, followed by the
-per-frame gather of the ranks' tiles to rank 0 and the un-tiling into the Film layout.  The frame is FIXED
-as N grows (the image is tiled across the GPUs), so scaling is "strong".
+A "step" is one complete frame of the config: all its samples per pixel (C3: 256 spp; --spp-per-step overrides)
+over the whole image, followed by the per-frame gather of the ranks' tiles to rank 0 and the un-tiling into the
+Film layout.  The frame is FIXED as N grows (the image is tiled across the GPUs), so scaling is "strong"; every
+GPU keeps ~66 M paths in flight (32 x N samples of its 1/N of the pixels).
 Rays = ray segments for which a closest-hit query ran, counted on the device.
 The scene, BVH and path state are resident in HBM before the timed region starts.
 """
@@ -28,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 NODE_BYTES = 128       # one BVH4 node visit: four child AABBs + four child refs = one cache line (csrc/bvh.h)
 TRI_BYTES = 48         # one leaf triangle test: 3 x float4 (P0+prim, P1+material, P2)
-RAY_FIXED_BYTES = 36   # k_intersect per ray: origin+dir read (2 x 16 B) + hit id write (4 B)
+RAY_FIXED_BYTES = 44   # traversal kernel per ray it walks: origin+dir (2 x 16 B) + hit id and d2 read (8 B) + hit id write (4 B)
 PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
 
 
@@ -40,7 +41,8 @@ def load_traffic(config, world, spp_step, sif):
             t = json.load(open(f))
         except Exception:
             continue
-        if (t.get("config"), t.get("n_gpus"), t.get("spp_per_step"), t.get("samples_in_flight")) == (config, world, spp_step, sif):
+        # a launch = one bounce of one batch of `sif` samples over this rank's pixels, whatever the step length
+        if (t.get("config"), t.get("n_gpus"), t.get("samples_in_flight")) == (config, world, sif):
             best = (t.get("hbm_bytes_per_launch"), f"{os.path.basename(f)}: {t.get('note', '')}")
     return best
 
@@ -48,15 +50,16 @@ def load_traffic(config, world, spp_step, sif):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md §8d)")
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=0, help="0 = the config's full sample count (C3: 256)")
     ap.add_argument("--samples-in-flight", type=int, default=0, help="0 = auto")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (rehearsal on a box with fewer GPUs)")
     ap.add_argument("--dump", default="", help="write the final frame as PPM/PFM with this path prefix")
     return ap.parse_args()
 
@@ -79,10 +82,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    if os.environ.get("PRT_BENCH_SAME_DEVICE"):  # rehearsal: all ranks share GPU 0 (use with --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- workload (outside the timed region: PLY parse, refinement, BVH build, upload) ----
     t_setup = time.time()
@@ -94,7 +102,7 @@ def main():
     r.set_variant(args.variant)
     n_tris = scene.n_triangles
     bvh = r.bvh_info()
-    spp_step = args.spp_per_step
+    spp_step = args.spp_per_step or spp_total  # a step = one complete frame of the config
     # many samples in flight: the late bounces are latency/tail-bound, more rays per launch hide it (288 GB HBM)
     sif = args.samples_in_flight or min(spp_step, max(1, (32 * 1920 * 1080 * world) // (W * H)))
     sif = max(1, min(sif, spp_step))
@@ -105,8 +113,9 @@ def main():
     # algorithmic traffic of the dominant kernel, measured with the instrumented traversal on sample 0
     trav = r.measure_traversal(sample=0)
     rays_sample = int(trav.rays_total)
+    rays_walked = int(trav.rays_traversed)  # rays that enter the BVH root box; the others never reach this kernel
     alg_bytes_sample = (NODE_BYTES * int(trav.bvh_node_visits) + TRI_BYTES * int(trav.bvh_tri_tests)
-                        + PRIM_BYTES * int(trav.prim_tests) + RAY_FIXED_BYTES * rays_sample)
+                        + RAY_FIXED_BYTES * rays_walked)
 
     def step():
         r.render_async(spp_step)
@@ -136,10 +145,11 @@ def main():
     rays_local = int(st.rays_total)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        rdev = device if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([rays_local], dtype=torch.int64, device=device)
+        c = torch.tensor([rays_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rays_total = int(c.item())
     else:
@@ -163,8 +173,9 @@ def main():
                     "kernel": "k_traverse4_persistent",
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
                     "alg_bytes_per_launch": int(bytes_per_launch),
-                    "node_visits_per_ray": round(trav.bvh_node_visits / max(1, rays_sample), 2),
-                    "tri_tests_per_ray": round(trav.bvh_tri_tests / max(1, rays_sample), 2),
+                    "rays_walked_frac": round(rays_walked / max(1, rays_sample), 3),
+                    "node_visits_per_walked_ray": round(trav.bvh_node_visits / max(1, rays_walked), 2),
+                    "tri_tests_per_walked_ray": round(trav.bvh_tri_tests / max(1, rays_walked), 2),
                     "stage_ms": {"raygen": round(st.raygen_ms, 3), "intersect": round(st.intersect_ms, 3),
                                  "shade": round(st.shade_ms, 3), "accumulate": round(st.accumulate_ms, 3)}}
 
@@ -202,8 +213,9 @@ def main():
                          "using the oracle's own median-split BVH for the mesh; the reference itself has no BVH "
                          "(linear scan over all primitives) and is unbuildable here"}
 
+    final = gather() if args.dump else None  # a collective: every rank takes part
     if args.dump and rank == 0:
-        rgb, wts = gather()
+        rgb, wts = final
         torch.cuda.synchronize()
         a = rgb.cpu().numpy().reshape(H, W, 3)
         w = wts.cpu().numpy().reshape(H, W)

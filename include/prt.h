@@ -134,7 +134,8 @@ typedef struct PrtStats {
     uint64_t bvh_tri_tests;
     uint64_t prim_tests;
     uint64_t node_lane_slots;          /* 64 x node-loop iterations of all waves: visits / slots = lane efficiency */
-    double scan_ms;                    /* analytic-primitive scan kernel (default variant) */
+    double scan_ms;                    /* analytic-primitive scan kernel (function-level entry points only) */
+    uint64_t rays_traversed;           /* prt_measure_traversal: rays that entered the BVH root box (walked the tree) */
 } PrtStats;
 
 typedef struct PrtBvhInfo {

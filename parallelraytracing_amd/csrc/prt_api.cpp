@@ -70,11 +70,9 @@ struct PrtContext {
     // ---- path state ----
     uint32_t S = 1;
     uint64_t cap_paths = 0;
-    PrtRayBuf rb[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    uint32_t* d_hit = nullptr;
-    float* d_hd2 = nullptr;
+    PrtRayBuf rb[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
     float4* d_rad = nullptr;
-    uint32_t* d_counts = nullptr;             // PRT_MAX_DEPTH + 1
+    uint32_t* d_counts = nullptr;             // (PRT_MAX_DEPTH + 2) x PRT_CNT_STRIDE: front/back ray counts per bounce
     unsigned long long* d_ray_stats = nullptr;  // PRT_MAX_DEPTH
     unsigned long long* d_trav_stats = nullptr; // 3
 
@@ -142,9 +140,9 @@ void free_path_state(PrtContext* c) {
         free_dev(c->rb[i].o);
         free_dev(c->rb[i].d);
         free_dev(c->rb[i].t);
+        free_dev(c->rb[i].hit);
+        free_dev(c->rb[i].hd2);
     }
-    free_dev(c->d_hit);
-    free_dev(c->d_hd2);
     free_dev(c->d_rad);
     c->cap_paths = 0;
 }
@@ -157,9 +155,9 @@ int ensure_path_state(PrtContext* c, uint64_t n_paths) {
         HIPCHECK(c, hipMalloc((void**)&c->rb[i].o, n * sizeof(float4)));
         HIPCHECK(c, hipMalloc((void**)&c->rb[i].d, n * sizeof(float4)));
         HIPCHECK(c, hipMalloc((void**)&c->rb[i].t, n * sizeof(float4)));
+        HIPCHECK(c, hipMalloc((void**)&c->rb[i].hit, n * sizeof(uint32_t)));
+        HIPCHECK(c, hipMalloc((void**)&c->rb[i].hd2, n * sizeof(float)));
     }
-    HIPCHECK(c, hipMalloc((void**)&c->d_hit, n * sizeof(uint32_t)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_hd2, n * sizeof(float)));
     HIPCHECK(c, hipMalloc((void**)&c->d_rad, n * sizeof(float4)));
     c->cap_paths = n;
     return PRT_OK;
@@ -167,10 +165,10 @@ int ensure_path_state(PrtContext* c, uint64_t n_paths) {
 
 int ensure_counters(PrtContext* c) {
     if (c->d_counts) return PRT_OK;
-    HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
     HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 4 * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
     HIPCHECK(c, hipMalloc((void**)&c->d_work, 2048));
@@ -272,32 +270,28 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
     if ((rc = ensure_spill(c))) return rc;
     EventPair ep{};
+    // front/back counters of every bounce start at zero (the producers add to them atomically)
+    HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
     if ((rc = begin_event(c, 0, &ep))) return rc;
-    prt_launch_raygen(c->stream, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts, max_depth);
+    prt_launch_raygen(c->stream, c->dsc, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts,
+                      c->d_work);
     if ((rc = end_event(c, &ep))) return rc;
     for (uint32_t d = 0; d < max_depth; ++d) {
         const PrtRayBuf& in = c->rb[d & 1];
         const PrtRayBuf& out = c->rb[(d + 1) & 1];
-        if (c->variant == 0) {
-            // default: coherent scan of the analytic primitives, then persistent BVH traversal
-            if ((rc = begin_event(c, 4, &ep))) return rc;
-            prt_launch_scan_prims(c->stream, c->dsc, in, c->d_hit, c->d_hd2, c->d_counts + d, c->d_work, n_paths, trav_stats);
-            if ((rc = end_event(c, &ep))) return rc;
-            if (c->dsc.n_nodes) {
-                if ((rc = begin_event(c, 1, &ep))) return rc;
-                prt_launch_traverse(c->stream, c->dsc, in, c->d_hit, c->d_hd2, c->d_counts + d, c->d_work, c->d_spill,
-                                    n_paths, c->bvh.max_depth, c->bvh.max_stack4, c->tune, trav_stats);
-                if ((rc = end_event(c, &ep))) return rc;
-            }
-        } else {
+        const uint32_t* front_count = c->d_counts + (size_t)d * PRT_CNT_STRIDE;
+        if (c->dsc.n_nodes) {  // only the front part of the buffer can hit a triangle
             if ((rc = begin_event(c, 1, &ep))) return rc;
-            prt_launch_intersect(c->stream, c->dsc, in, c->d_hit, c->d_counts + d, n_paths, stack_depth, c->variant,
-                                 trav_stats);
+            if (c->variant == 0)
+                prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
+                                    c->bvh.max_stack4, c->tune, trav_stats);
+            else
+                prt_launch_intersect(c->stream, c->dsc, in, front_count, n_paths, stack_depth, c->variant, trav_stats);
             if ((rc = end_event(c, &ep))) return rc;
+            ++c->stats.intersect_launches;
         }
-        ++c->stats.intersect_launches;
         if ((rc = begin_event(c, 2, &ep))) return rc;
-        prt_launch_shade(c->stream, c->dsc, in, c->d_hit, out, c->d_rad, c->d_counts, d, max_depth, n_paths);
+        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths);
         if ((rc = end_event(c, &ep))) return rc;
     }
     if (accumulate) {
@@ -305,7 +299,6 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, c->d_counts, max_depth,
                               c->d_ray_stats);
         if ((rc = end_event(c, &ep))) return rc;
-        c->dead_paths += (uint64_t)S_cur * (c->tm.n_pix_local - c->valid_local);
         c->stats.samples += S_cur;
     }
     HIPCHECK(c, hipGetLastError());
@@ -474,6 +467,14 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.pad = kPadCoeff;
     d.extent = extent;
     memcpy(d.sky, s->sky, sizeof(d.sky));
+    for (int k = 0; k < 3; ++k) {
+        d.root_min[k] = FLT_MAX;
+        d.root_max[k] = -FLT_MAX;
+    }
+    for (size_t t = 0; t < (size_t)n_tris * 9; ++t) {
+        d.root_min[t % 3] = std::min(d.root_min[t % 3], verts[t]);
+        d.root_max[t % 3] = std::max(d.root_max[t % 3], verts[t]);
+    }
     c->has_scene = true;
     if (!c->has_device) return PRT_OK;  // host-only context: BVH built, nothing to upload
 
@@ -737,18 +738,19 @@ int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float
     PrtHit* d_h = (PrtHit*)(base + ((2 * b3 + 15) & ~(size_t)15));
     HIPCHECK(c, hipMemcpyAsync(d_o, origins, b3, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipMemcpyAsync(d_d, dirs, b3, hipMemcpyHostToDevice, c->stream));
-    uint32_t* cnt = c->d_counts + PRT_MAX_DEPTH + 1;  // a counter slot the render loop never uses
+    uint32_t* cnt = c->d_counts + (size_t)(PRT_MAX_DEPTH + 1) * PRT_CNT_STRIDE;  // a counter slot the render loop never uses
     prt_launch_pack_rays(c->stream, n, d_o, d_d, c->rb[0], cnt);
     const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
-    if (c->variant == 0) {
-        if ((rc = ensure_spill(c))) return rc;
-        prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, n, nullptr);
-        if (c->dsc.n_nodes)
-            prt_launch_traverse(c->stream, c->dsc, c->rb[0], c->d_hit, c->d_hd2, cnt, c->d_work, c->d_spill, n, c->bvh.max_depth, c->bvh.max_stack4, c->tune, nullptr);
-    } else {
-        prt_launch_intersect(c->stream, c->dsc, c->rb[0], c->d_hit, cnt, n, stack_depth, c->variant, nullptr);
+    if ((rc = ensure_spill(c))) return rc;
+    prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], cnt, c->d_work, n, nullptr);
+    if (c->dsc.n_nodes) {
+        if (c->variant == 0)
+            prt_launch_traverse(c->stream, c->dsc, c->rb[0], cnt, c->d_work, c->d_spill, n, c->bvh.max_depth,
+                                c->bvh.max_stack4, c->tune, nullptr);
+        else
+            prt_launch_intersect(c->stream, c->dsc, c->rb[0], cnt, n, stack_depth, c->variant, nullptr);
     }
-    prt_launch_hit_records(c->stream, c->dsc, n, c->rb[0], c->d_hit, d_h);
+    prt_launch_hit_records(c->stream, c->dsc, n, c->rb[0], d_h);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(hits, d_h, bh, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -819,9 +821,6 @@ int prt_get_stats(PrtContext* c, PrtStats* out) {
             s.rays_per_depth[d] = h[d];
             s.rays_total += h[d];
         }
-        // slot 0 counted the dead (outside-the-image) lanes of partial tiles as well
-        s.rays_per_depth[0] -= std::min<uint64_t>(c->dead_paths, s.rays_per_depth[0]);
-        s.rays_total -= std::min<uint64_t>(c->dead_paths, s.rays_total);
     }
     *out = s;
     return PRT_OK;
@@ -853,21 +852,22 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     unsigned long long t[4];
-    uint32_t cnt[PRT_MAX_DEPTH + 2];
+    std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
-    HIPCHECK(c, hipMemcpy(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(cnt.data(), c->d_counts, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
+    uint64_t front = 0;
     for (uint32_t d = 0; d < max_depth; ++d) {
-        out->rays_per_depth[d] = cnt[d];
-        out->rays_total += cnt[d];
+        const uint64_t n = (uint64_t)cnt[(size_t)d * PRT_CNT_STRIDE] + cnt[(size_t)d * PRT_CNT_STRIDE + 32];
+        front += cnt[(size_t)d * PRT_CNT_STRIDE];
+        out->rays_per_depth[d] = n;
+        out->rays_total += n;
     }
-    const uint64_t dead = c->tm.n_pix_local - c->valid_local;
-    out->rays_per_depth[0] -= dead;
-    out->rays_total -= dead;
+    out->rays_traversed = front;
     out->samples = 1;
     out->bvh_node_visits = t[0];
     out->bvh_tri_tests = t[1];
-    out->prim_tests = t[2];
+    out->prim_tests = (uint64_t)c->prims.size() * out->rays_total;  // every ray scans every analytic primitive
     out->node_lane_slots = t[3];
     return PRT_OK;
 }

@@ -37,6 +37,7 @@ struct DevScene {
     uint32_t n_tris;
     float pad;     // culling pad coefficient (2^-18): pad_ray = pad * (|o|_1 + extent)
     float extent;  // max |coordinate| of any mesh vertex
+    float root_min[3], root_max[3];  // bounds of all triangles (BVH root box)
     float sky[3];
 };
 
@@ -59,25 +60,27 @@ struct PrtTravTuning {
 };
 
 struct PrtRayBuf {
-    float4* o;  // origin.xyz, path id
-    float4* d;  // direction.xyz, rng state
-    float4* t;  // throughput.rgb, -
+    float4* o;      // origin.xyz, path id
+    float4* d;      // direction.xyz, rng state
+    float4* t;      // throughput.rgb, -
+    uint32_t* hit;  // closest-hit id so far (producer: analytic scan; traversal: final)
+    float* hd2;     // its world distance^2
 };
 
-void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
+#define PRT_CNT_STRIDE 64u  // uint32 per bounce in the counter array: [0] front count, [32] back count
+
+void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t max_depth);
-void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, float* hd2,
-                           const uint32_t* count_ptr, uint32_t* work, uint32_t max_rays, unsigned long long* stats);
-void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
-                         const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
-                         uint32_t tree_depth, uint32_t stack4, const PrtTravTuning& tune, unsigned long long* stats);
-void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
-                          const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
-                          unsigned long long* stats);
-void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* hit,
-                      const PrtRayBuf& out, float4* rad, uint32_t* counts, uint32_t depth, uint32_t max_depth,
-                      uint32_t max_rays);
+                       uint32_t* work);
+void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
+                           uint32_t* work, uint32_t max_rays, unsigned long long* stats);
+void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
+                         uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
+                         const PrtTravTuning& tune, unsigned long long* stats);
+void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
+                          uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
+void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
+                      uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            const uint32_t* counts, uint32_t max_depth, unsigned long long* ray_stats);
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,
@@ -88,8 +91,7 @@ void prt_launch_camera_rays(hipStream_t st, const DevCamera& cam, uint32_t n, co
                             float* o, float* d);
 void prt_launch_pack_rays(hipStream_t st, uint32_t n, const float* o, const float* d, const PrtRayBuf& out,
                           uint32_t* counts);
-void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, const uint32_t* hit,
-                            PrtHit* out);
+void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, PrtHit* out);
 void prt_launch_scatter_test(hipStream_t st, const DevScene& sc, uint32_t n, const float* in_d, const PrtHit* hits,
                              uint32_t* rng_io, uint32_t* scattered, float* atten, float* emitted, float* o_out,
                              float* d_out);

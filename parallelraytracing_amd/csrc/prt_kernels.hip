@@ -30,6 +30,54 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Two-sided ray buffers.  Every producer (k_raygen, k_shade) classifies the ray it emits: rays that can still
+// hit a triangle (they enter the BVH root box before their analytic hit) are packed from the FRONT of the next
+// buffer, all others from the BACK.  The traversal kernel only sees the front part; the shade kernel sees both.
+// Per bounce d: counts[d*64] = front count A_d, counts[d*64 + 32] = back count B_d (separate 128-B lines).
+// ---------------------------------------------------------------------------------------------------------
+#define CNT_STRIDE PRT_CNT_STRIDE
+#define CNT_A(c, d) (c)[(d) * CNT_STRIDE]
+#define CNT_B(c, d) (c)[(d) * CNT_STRIDE + 32u]
+#define PRODUCER_BLOCK 1024
+
+// Slot reservation for a 1024-thread block with ONE atomic per side (a counter word sustains only ~88
+// returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
+// reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
+// Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
+PRT_DEV uint32_t block_alloc2(bool front, bool back, uint32_t* cntA, uint32_t* cntB, uint32_t cap) {
+    __shared__ uint32_t s_a[PRODUCER_BLOCK / 64], s_b[PRODUCER_BLOCK / 64];
+    __shared__ uint32_t s_base_a, s_base_b;
+    const unsigned long long ma = __ballot(front), mb = __ballot(back);
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_a[wave] = (uint32_t)__popcll(ma);
+        s_b[wave] = (uint32_t)__popcll(mb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tb = 0;
+        for (uint32_t w = 0; w < PRODUCER_BLOCK / 64; ++w) {
+            ta += s_a[w];
+            tb += s_b[w];
+        }
+        s_base_a = ta ? atomicAdd(cntA, ta) : 0u;
+        s_base_b = tb ? atomicAdd(cntB, tb) : 0u;
+    }
+    __syncthreads();
+    uint32_t slot = 0xFFFFFFFFu;
+    if (front) {
+        uint32_t j = s_base_a + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) j += s_a[w];
+        slot = j;
+    } else if (back) {
+        uint32_t j = s_base_b + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) j += s_b[w];
+        slot = cap - 1u - j;
+    }
+    return slot;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Tile map: 8x8-pixel tiles, tile t (row-major) belongs to rank t % world.
 // ---------------------------------------------------------------------------------------------------------
 PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t& y) {
@@ -44,33 +92,41 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 // ---------------------------------------------------------------------------------------------------------
 // Ray generation (GenerateCameraRaysKernel, renderer.cu:186-204; pixel centres, cpu/renderer.cpp:45)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_raygen(DevCamera cam, PrtTileMap tm, uint32_t n_paths, uint32_t first_sample,
-                                                uint32_t seed, float4* __restrict__ ro, float4* __restrict__ rd,
-                                                float4* __restrict__ rt, float4* __restrict__ rad,
-                                                uint32_t* __restrict__ counts, uint32_t max_depth) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) {
-        counts[0] = n_paths;
-        for (uint32_t d = 1; d <= max_depth; ++d) counts[d] = 0;
+__device__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0);
+
+__global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t n_paths,
+                                                            uint32_t first_sample, uint32_t seed,
+                                                            float4* __restrict__ ro, float4* __restrict__ rd,
+                                                            float4* __restrict__ rt, uint32_t* __restrict__ hit,
+                                                            float* __restrict__ hd2, float4* __restrict__ rad,
+                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ work) {
+    const uint32_t i = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
+    if (i < 8u) work[32u * i] = 0u;  // chunk cursors of the traversal kernel that follows on the stream
+    bool front = false, back = false;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    uint32_t rng = 0, id0 = HIT_MISS;
+    float d2_0 = 3.402823466e+38f;
+    if (i < n_paths) {
+        const uint32_t s_local = i / tm.n_pix_local;
+        const uint32_t pl = i - s_local * tm.n_pix_local;
+        uint32_t x, y;
+        if (tile_pixel(tm, pl, x, y)) {
+            camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
+            rng = path_seed(y * tm.W + x, first_sample + s_local, seed);
+            front = classify_ray(sc, o, d, id0, d2_0);
+            back = !front;
+        } else {
+            rad[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // lanes of partial tiles outside the image: no path
+        }
     }
-    if (i >= n_paths) return;
-    const uint32_t s_local = i / tm.n_pix_local;
-    const uint32_t pl = i - s_local * tm.n_pix_local;
-    uint32_t x, y;
-    if (!tile_pixel(tm, pl, x, y)) {
-        // outside the image: a dead path (keeps slot numbering dense and deterministic)
-        ro[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(i));
-        rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
+    const uint32_t slot = block_alloc2(front, back, &CNT_A(counts, 0), &CNT_B(counts, 0), n_paths);
+    if (slot != 0xFFFFFFFFu) {
+        ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+        rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
+        rt[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+        hit[slot] = id0;
+        hd2[slot] = d2_0;
     }
-    f3 o, d;
-    camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
-    const uint32_t rng = path_seed(y * tm.W + x, first_sample + s_local, seed);
-    ro[i] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-    rd[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-    rt[i] = make_float4(1.f, 1.f, 1.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -101,6 +157,34 @@ PRT_DEV void scan_analytic(const DevScene& sc, f3 o, f3 d, Closest& best, uint32
 PRT_DEV float limit_from_d2(float d2, float pad) {
     // Upper bound on the local ray parameter of anything that could still win (d2' <= d2).
     return (d2 < 3.0e38f) ? __builtin_sqrtf(d2) * 1.0000153f + 4.0f * pad : 3.4e38f;
+}
+
+// What every producer does for the ray it emits: the linear scan over the analytic primitives (its result is the
+// initial "best" of the traversal) and the decision whether the BVH has to be walked at all: only if the ray enters
+// the (per-ray padded) root box before the analytic hit, by the same conservative test the traversal applies.
+__device__ __forceinline__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0) {
+    Closest best;
+    best.d2 = 3.402823466e+38f;  // FLT_MAX (primitive.cpp:23)
+    best.id = HIT_MISS;
+    best.prim = 0xFFFFFFFFu;
+    uint32_t n_tests = 0;
+    scan_analytic(sc, o, d, best, n_tests);
+    id0 = best.id;
+    d2_0 = best.d2;
+    if (sc.n_nodes == 0u) return false;
+    const f3 ld = normalize3(d);
+    const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+    const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+    const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+    const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+    const float x0 = __builtin_fmaf(sc.root_min[0], ix, -(o.x + pad) * ix), x1 = __builtin_fmaf(sc.root_max[0], ix, -(o.x - pad) * ix);
+    const float y0 = __builtin_fmaf(sc.root_min[1], iy, -(o.y + pad) * iy), y1 = __builtin_fmaf(sc.root_max[1], iy, -(o.y - pad) * iy);
+    const float z0 = __builtin_fmaf(sc.root_min[2], iz, -(o.z + pad) * iz), z1 = __builtin_fmaf(sc.root_max[2], iz, -(o.z - pad) * iz);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
+                                     __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
+                                     __builtin_fminf(__builtin_fmaxf(z0, z1), limit_from_d2(d2_0, pad)));
+    return tn <= tf * 1.0000005f;
 }
 
 // Variant 1 (kept for A/B runs): one loop, each iteration is either a node step or a leaf, per lane.
@@ -800,38 +884,37 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-// Compaction: the survivors of a 1024-thread block reserve their slots in the next bounce's buffer with ONE
-// atomic (wave ballots -> LDS -> thread 0).  A single counter word sustains only ~88 returning atomics/us
-// (MI355X_MICROARCH.md "dequeue"), so the per-wave form (the wave64 equivalent of the reference's
-// warp-aggregated AllocateSlot, renderer.cu:43-67) costs ~0.9 ms per 8 M rays; per-block it is 16x fewer.
-#define SHADE_BLOCK 1024
+#define SHADE_BLOCK PRODUCER_BLOCK
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
                                                       float4* __restrict__ nd, float4* __restrict__ nt,
+                                                      uint32_t* __restrict__ nhit, float* __restrict__ nhd2,
                                                       float4* __restrict__ rad, uint32_t* __restrict__ counts,
-                                                      uint32_t depth, uint32_t max_depth) {
-    __shared__ uint32_t s_cnt[SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base;
-    const uint32_t count = counts[depth];
+                                                      uint32_t* __restrict__ work, uint32_t depth, uint32_t max_depth,
+                                                      uint32_t cap) {
+    const uint32_t nA = CNT_A(counts, depth), nB = CNT_B(counts, depth);
+    const uint32_t count = nA + nB;
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // whole block exits together
     const uint32_t k = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
-    bool want = false;
+    if (k < 8u) work[32u * k] = 0u;  // chunk cursors of the next bounce's traversal kernel
+    bool front = false, back = false;
     float4 O2, D2, T2;
+    uint32_t id0 = HIT_MISS;
+    float d2_0 = 3.402823466e+38f;
     if (k < count) {
-        const float4 O = ro[k];
-        const float4 D = rd[k];
-        const float4 T = rt[k];
-        const uint32_t id = hit[k];
+        const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
+        const float4 O = ro[src];
+        const float4 D = rd[src];
+        const float4 T = rt[src];
+        const uint32_t id = hit[src];
         const uint32_t pid = __float_as_uint(O.w);
         uint32_t rng = __float_as_uint(D.w);
         const f3 thr = mk3(T.x, T.y, T.z);
-        if (id == HIT_DEAD) {
-            // nothing: k_raygen already zeroed rad[pid]
-        } else if (id == HIT_MISS) {
+        if (id == HIT_MISS) {
             const f3 L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);
             rad[pid] = make_float4(L.x, L.y, L.z, 0.f);
-        } else {
+        } else if (id != HIT_DEAD) {
             const f3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
             WorldHit w;
             world_hit_from_id(sc, id, o, d, w);
@@ -853,27 +936,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
                 O2 = make_float4(so.x, so.y, so.z, O.w);
                 D2 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(rng));
                 T2 = make_float4(t2.x, t2.y, t2.z, 0.f);
-                want = true;
+                front = classify_ray(sc, so, d2, id0, d2_0);
+                back = !front;
             }
         }
     }
-    const unsigned long long mask = __ballot(want);
-    const uint32_t lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < SHADE_BLOCK / 64; ++w) total += s_cnt[w];
-        s_base = total ? atomicAdd(&counts[depth + 1u], total) : 0u;
-    }
-    __syncthreads();
-    if (want) {
-        uint32_t slot = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) slot += s_cnt[w];
+    const uint32_t slot = block_alloc2(front, back, &CNT_A(counts, depth + 1u), &CNT_B(counts, depth + 1u), cap);
+    if (slot != 0xFFFFFFFFu) {
         no[slot] = O2;
         nd[slot] = D2;
         nt[slot] = T2;
+        nhit[slot] = id0;
+        nhd2[slot] = d2_0;
     }
 }
 
@@ -887,7 +961,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
                                                     uint32_t max_depth, unsigned long long* __restrict__ ray_stats) {
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
     if (pl == 0) {
-        for (uint32_t d = 0; d < max_depth; ++d) ray_stats[d] += counts[d];
+        for (uint32_t d = 0; d < max_depth; ++d) ray_stats[d] += (unsigned long long)CNT_A(counts, d) + CNT_B(counts, d);
     }
     if (pl >= tm.n_pix_local) return;
     uint32_t x, y;
@@ -968,7 +1042,7 @@ __global__ void k_camera_rays(DevCamera cam, uint32_t n, const float* __restrict
 __global__ void k_pack_rays(uint32_t n, const float* __restrict__ o, const float* __restrict__ d,
                             float4* __restrict__ ro, float4* __restrict__ rd, uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) counts[0] = n;
+    if (i == 0) counts[0] = n;  // front count of the slot it was given
     if (i >= n) return;
     ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], __uint_as_float(i));
     rd[i] = make_float4(d[3 * i], d[3 * i + 1], d[3 * i + 2], 0.f);
@@ -1041,21 +1115,20 @@ __global__ void k_scatter_test(DevScene sc, uint32_t n, const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 
-void prt_launch_raygen(hipStream_t st, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
+void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t max_depth) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_paths)), dim3(256), 0, st, cam, tm, n_paths, first_sample, seed,
-                       out.o, out.d, out.t, rad, counts, max_depth);
+                       uint32_t* work) {
+    hipLaunchKernelGGL(k_raygen, dim3((n_paths + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK), dim3(PRODUCER_BLOCK), 0, st, sc,
+                       cam, tm, n_paths, first_sample, seed, out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work);
 }
 
-void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, float* hd2,
-                           const uint32_t* count_ptr, uint32_t* work, uint32_t max_rays, unsigned long long* stats) {
-    hipLaunchKernelGGL(k_scan_prims, dim3(blocks_for(max_rays)), dim3(256), 0, st, sc, in.o, in.d, hit, hd2, count_ptr,
-                       work, stats);
+void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
+                           uint32_t* work, uint32_t max_rays, unsigned long long* stats) {
+    hipLaunchKernelGGL(k_scan_prims, dim3(blocks_for(max_rays)), dim3(256), 0, st, sc, in.o, in.d, in.hit, in.hd2,
+                       count_ptr, work, stats);
 }
 
-void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit, const float* hd2,
-                         const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
+void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
                          uint32_t tree_depth, uint32_t stack4, const PrtTravTuning& tune, unsigned long long* stats) {
     uint32_t g = tune.grid_blocks;
     const uint32_t need = blocks_for(max_rays);
@@ -1065,10 +1138,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 #define PRT_LAUNCH_T(L, W, SP)                                                                                        \
     do {                                                                                                              \
         if (stats)                                                                                                    \
-            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, hit, hd2,  \
+            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,  \
                                count_ptr, work, spill, tune, stats);                                                  \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, hit, hd2, \
+            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2, \
                                count_ptr, work, spill, tune, stats);                                                  \
     } while (0)
     // tree_depth <= stack entries in LDS: no spill code at all; deeper trees keep 31 entries in LDS + global spill
@@ -1077,10 +1150,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 #define PRT_LAUNCH_T4(L, W, SP)                                                                                        \
     do {                                                                                                               \
         if (stats)                                                                                                     \
-            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, hit, hd2,  \
+            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,  \
                                count_ptr, work, spill, tune, stats);                                                   \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, hit, hd2, \
+            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2, \
                                count_ptr, work, spill, tune, stats);                                                   \
     } while (0)
         if (stack4 <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T4(24, 6, false);
@@ -1098,12 +1171,11 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 }
 
 // Variants 1 (while-while) and 2 (one-loop): the fused one-thread-per-ray kernel, kept for A/B runs.
-void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, uint32_t* hit,
-                          const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
+void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
                           unsigned long long* stats) {
     const dim3 grid(blocks_for(max_rays)), block(256);
 #define PRT_LAUNCH_I(S, T, V) \
-    hipLaunchKernelGGL((k_intersect<S, T, V>), grid, block, 0, st, sc, in.o, in.d, hit, count_ptr, stats)
+    hipLaunchKernelGGL((k_intersect<S, T, V>), grid, block, 0, st, sc, in.o, in.d, in.hit, count_ptr, stats)
     const bool deep = stack_depth > 31;
     if (stats) {
         if (variant == 2) { if (deep) PRT_LAUNCH_I(63, true, 1); else PRT_LAUNCH_I(31, true, 1); }
@@ -1115,11 +1187,11 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 #undef PRT_LAUNCH_I
 }
 
-void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* hit,
-                      const PrtRayBuf& out, float4* rad, uint32_t* counts, uint32_t depth, uint32_t max_depth,
-                      uint32_t max_rays) {
-    hipLaunchKernelGGL(k_shade, dim3((uint32_t)((max_rays + SHADE_BLOCK - 1) / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc,
-                       in.o, in.d, in.t, hit, out.o, out.d, out.t, rad, counts, depth, max_depth);
+void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
+                      uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap) {
+    hipLaunchKernelGGL(k_shade, dim3((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc,
+                       in.o, in.d, in.t, in.hit, out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, depth,
+                       max_depth, cap);
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
@@ -1150,9 +1222,8 @@ void prt_launch_pack_rays(hipStream_t st, uint32_t n, const float* o, const floa
     hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n)), dim3(256), 0, st, n, o, d, out.o, out.d, counts);
 }
 
-void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, const uint32_t* hit,
-                            PrtHit* out) {
-    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(n)), dim3(256), 0, st, sc, n, in.o, in.d, hit, out);
+void prt_launch_hit_records(hipStream_t st, const DevScene& sc, uint32_t n, const PrtRayBuf& in, PrtHit* out) {
+    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(n)), dim3(256), 0, st, sc, n, in.o, in.d, in.hit, out);
 }
 
 void prt_launch_scatter_test(hipStream_t st, const DevScene& sc, uint32_t n, const float* in_d, const PrtHit* hits,

@@ -91,9 +91,19 @@ class FilmGather:
 
     def __call__(self):
         """Enqueue gather + resolve on the current stream; returns (rgb, weight) on rank 0, else None."""
+        import torch
         import torch.distributed as dist
         if self.world > 1:
-            dist.gather(self.local, self.parts if self.rank == 0 else None, dst=0, group=self.group)
+            if dist.get_backend(self.group) == "gloo":
+                # rehearsal path (several ranks sharing one GPU, or no RCCL): stage through host memory
+                torch.cuda.current_stream().synchronize()
+                host = self.local.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(host, parts, dst=0, group=self.group)
+                if self.rank == 0:
+                    self.gathered.copy_(torch.cat(parts))
+            else:
+                dist.gather(self.local, self.parts if self.rank == 0 else None, dst=0, group=self.group)
             src = self.gathered
         else:
             src = self.local

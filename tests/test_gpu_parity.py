@@ -108,6 +108,27 @@ def test_closest_hit_refined_mesh_vs_oracle_bvh_bit_exact():
     assert util.hits_equal(got, want) == []
 
 
+def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
+    """The headline mesh (dragon refined to 870,000 triangles; deep 4-wide tree -> LDS + global-spill stack)."""
+    scene, cam, W, H, spp, depth = prt.scenes.config("C3")
+    r, _, _ = make_renderer(scene, 64, 36, cam=prt.Camera(cam.position, width=64, height=36))
+    info = r.bvh_info()
+    assert info.n_triangles == 870_000 and info.max_stack4 <= 63
+    rng = np.random.default_rng(12)
+    o, d = _mesh_rays(rng, 30000)
+    px = rng.uniform(0, 64, 10000).astype(np.float32)
+    py = rng.uniform(0, 36, 10000).astype(np.float32)
+    o2, d2 = r.camera_rays(px, py)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    got = r.closest_hit(o, d)
+    want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=True, n_threads=8)
+    assert util.hits_equal(got, want) == []
+    assert (got["prim"] >= 2).sum() > 8000
+    for v in (1, 2):  # the one-thread-per-ray kernels over the binary tree give the same hits
+        r.set_variant(v)
+        assert util.hits_equal(r.closest_hit(o, d), want) == []
+
+
 def test_scatter_bit_exact_all_materials():
     scene = prt.Scene("DEFAULT")
     scene.AddMetal((0.9, 0.8, 0.7), 0.0)

@@ -86,8 +86,8 @@ def main():
         if args.eff:
             apply(d)
             tr = r.measure_traversal()
-            line += (f"  eff {tr.bvh_node_visits / max(1, tr.node_lane_slots):.3f} nodes/ray {tr.bvh_node_visits / tr.rays_total:.2f}"
-                     f" tris/ray {tr.bvh_tri_tests / tr.rays_total:.2f}")
+            line += (f"  eff {tr.bvh_node_visits / max(1, tr.node_lane_slots):.3f} walked {tr.rays_traversed / tr.rays_total:.3f}"
+                     f" nodes/walked {tr.bvh_node_visits / max(1, tr.rays_traversed):.2f} tris/walked {tr.bvh_tri_tests / max(1, tr.rays_traversed):.2f}")
         print(line, flush=True)
 
 
