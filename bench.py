@@ -33,6 +33,10 @@ RAY_FIXED_BYTES = 44   # traversal kernel per ray it walks: origin+dir (2 x 16 B
 PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
 
 
+MESH_OF = {"C2": "bunny.ply refined by longest-edge bisection", "C3": "dragon.ply refined by longest-edge bisection",
+           "C4": "dragon.ply refined by longest-edge bisection", "C5": "12 baked copies of the refined dragon.ply"}
+
+
 def load_traffic(config, world, spp_step, sif):
     import glob
     best = (None, "no committed PMC profile matches this configuration")
@@ -232,7 +236,7 @@ def main():
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: dragon.ply refined to {n_tris} triangles + ground quad + emissive quad, "
+            "config": {"workload": f"{args.config}: {MESH_OF[args.config]} = {n_tris} triangles + ground quad + emissive quad, "
                                    f"{W}x{H}, max_depth {max_depth} segments (= {max_depth - 1} bounces), "
                                    f"{spp_step} spp per step ({args.steps * spp_step} spp timed of the config's {spp_total}), "
                                    f"image tiled over {world} GPU(s) + per-step gather to rank 0",
