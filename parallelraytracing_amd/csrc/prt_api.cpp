@@ -171,8 +171,9 @@ int ensure_counters(PrtContext* c) {
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_work, 2048));
-    HIPCHECK(c, hipMemset(c->d_work, 0, 2048));
+    // [0..255] chunk cursors (one 128-B line per XCD), [256] watchdog flag, [512] overflow count, [513..] overflow list
+    HIPCHECK(c, hipMalloc((void**)&c->d_work, (513 + (1u << 20)) * sizeof(uint32_t)));
+    HIPCHECK(c, hipMemset(c->d_work, 0, (513 + (1u << 20)) * sizeof(uint32_t)));
     return PRT_OK;
 }
 
@@ -603,8 +604,8 @@ int prt_synchronize(PrtContext* c) {
         uint32_t w = 0;
         HIPCHECK(c, hipMemcpy(&w, c->d_work + 256, sizeof(w), hipMemcpyDeviceToHost));
         if (w) {
-            HIPCHECK(c, hipMemset(c->d_work, 0, 2048));
-            return fail(c, PRT_ERR_HIP, "traversal watchdog tripped: a wave exceeded its iteration cap");
+            HIPCHECK(c, hipMemset(c->d_work, 0, 2052));
+            return fail(c, PRT_ERR_HIP, w & 2u ? "traversal stack-overflow list full" : "traversal watchdog tripped: a wave exceeded its iteration cap");
         }
     }
     return PRT_OK;
@@ -858,7 +859,8 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     memset(out, 0, sizeof(*out));
     uint64_t front = 0;
     for (uint32_t d = 0; d < max_depth; ++d) {
-        const uint64_t n = (uint64_t)cnt[(size_t)d * PRT_CNT_STRIDE] + cnt[(size_t)d * PRT_CNT_STRIDE + 32];
+        const uint64_t n = (uint64_t)cnt[(size_t)d * PRT_CNT_STRIDE] + cnt[(size_t)d * PRT_CNT_STRIDE + 32] +
+                           cnt[(size_t)d * PRT_CNT_STRIDE + 16];  // front + back + finished in the producer
         front += cnt[(size_t)d * PRT_CNT_STRIDE];
         out->rays_per_depth[d] = n;
         out->rays_total += n;
@@ -902,7 +904,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1)) c->tune.wide = (uint32_t)value;
-    else if (n == "stack_lds" && (value == 24 || value == 31 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 2 || value == 24 || value == 31 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
     else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;
     else return fail(c, PRT_ERR_INVALID, "unknown parameter or bad value: %s = %d", name, value);

@@ -67,7 +67,7 @@ struct PrtRayBuf {
     float* hd2;     // its world distance^2
 };
 
-#define PRT_CNT_STRIDE 64u  // uint32 per bounce in the counter array: [0] front count, [32] back count
+#define PRT_CNT_STRIDE 64u  // uint32 per bounce in the counter array: [0] front, [32] back, [16] finished-in-producer counts
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,

@@ -38,30 +38,35 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 #define CNT_STRIDE PRT_CNT_STRIDE
 #define CNT_A(c, d) (c)[(d) * CNT_STRIDE]
 #define CNT_B(c, d) (c)[(d) * CNT_STRIDE + 32u]
+#define CNT_C(c, d) (c)[(d) * CNT_STRIDE + 16u]
 #define PRODUCER_BLOCK 1024
 
 // Slot reservation for a 1024-thread block with ONE atomic per side (a counter word sustains only ~88
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
 // reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
 // Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
-PRT_DEV uint32_t block_alloc2(bool front, bool back, uint32_t* cntA, uint32_t* cntB, uint32_t cap) {
-    __shared__ uint32_t s_a[PRODUCER_BLOCK / 64], s_b[PRODUCER_BLOCK / 64];
+PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, uint32_t* cntB, uint32_t* cntC,
+                              uint32_t cap) {
+    __shared__ uint32_t s_a[PRODUCER_BLOCK / 64], s_b[PRODUCER_BLOCK / 64], s_c[PRODUCER_BLOCK / 64];
     __shared__ uint32_t s_base_a, s_base_b;
-    const unsigned long long ma = __ballot(front), mb = __ballot(back);
+    const unsigned long long ma = __ballot(front), mb = __ballot(back), mc = __ballot(done);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     if (lane == 0) {
         s_a[wave] = (uint32_t)__popcll(ma);
         s_b[wave] = (uint32_t)__popcll(mb);
+        s_c[wave] = (uint32_t)__popcll(mc);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t ta = 0, tb = 0;
+        uint32_t ta = 0, tb = 0, tc = 0;
         for (uint32_t w = 0; w < PRODUCER_BLOCK / 64; ++w) {
             ta += s_a[w];
             tb += s_b[w];
+            tc += s_c[w];
         }
         s_base_a = ta ? atomicAdd(cntA, ta) : 0u;
         s_base_b = tb ? atomicAdd(cntB, tb) : 0u;
+        if (tc) atomicAdd(cntC, tc);  // ray segments finished inside the producer: counted, never stored
     }
     __syncthreads();
     uint32_t slot = 0xFFFFFFFFu;
@@ -93,6 +98,7 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 // Ray generation (GenerateCameraRaysKernel, renderer.cu:186-204; pixel centres, cpu/renderer.cpp:45)
 // ---------------------------------------------------------------------------------------------------------
 __device__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0);
+__device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, f3& L);
 
 __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t n_paths,
                                                             uint32_t first_sample, uint32_t seed,
@@ -102,7 +108,8 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ work) {
     const uint32_t i = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
     if (i < 8u) work[32u * i] = 0u;  // chunk cursors of the traversal kernel that follows on the stream
-    bool front = false, back = false;
+    if (i == 8u) work[512] = 0u;     // its overflow-list counter
+    bool front = false, back = false, done = false;
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     uint32_t rng = 0, id0 = HIT_MISS;
     float d2_0 = 3.402823466e+38f;
@@ -114,12 +121,15 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
             rng = path_seed(y * tm.W + x, first_sample + s_local, seed);
             front = classify_ray(sc, o, d, id0, d2_0);
-            back = !front;
+            f3 L;
+            done = ends_here(sc, front, id0, mk3(1.f, 1.f, 1.f), L);
+            if (done) rad[i] = make_float4(L.x, L.y, L.z, 0.f);
+            back = !front && !done;
         } else {
             rad[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // lanes of partial tiles outside the image: no path
         }
     }
-    const uint32_t slot = block_alloc2(front, back, &CNT_A(counts, 0), &CNT_B(counts, 0), n_paths);
+    const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
     if (slot != 0xFFFFFFFFu) {
         ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
         rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
@@ -185,6 +195,24 @@ __device__ __forceinline__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uin
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
                                      __builtin_fminf(__builtin_fmaxf(z0, z1), limit_from_d2(d2_0, pad)));
     return tn <= tf * 1.0000005f;
+}
+
+// A classified ray that cannot hit a triangle AND whose analytic result ends the path (it misses everything, or it
+// hits an emissive primitive, which never scatters: material.h:119-122) needs no slot in the next buffer: the
+// value the next k_shade would write for it is already known.  Returns true and that radiance in that case.
+__device__ __forceinline__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, f3& L) {
+    if (front) return false;
+    if (id0 == HIT_MISS) {
+        L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);  // the miss branch of k_shade
+        return true;
+    }
+    const uint32_t m = sc.prims[id0].material;
+    if (sc.mat_type[m] == 4u) {
+        const float4 e = sc.mat_rgbs[m];
+        L = thr * mk3(e.x, e.y, e.z);  // throughput * emitted, then the path stops
+        return true;
+    }
+    return false;
 }
 
 // Variant 1 (kept for A/B runs): one loop, each iteration is either a node step or a leaf, per lane.
@@ -284,6 +312,7 @@ PRT_DEV void traverse_ifif(const DevScene& sc, f3 o, f3 d, Closest& best, uint32
 #define NODE_DONE 0x7FFFFFFF
 #define LEAF_NONE 0x7FFFFFFE
 #define NEED_POP 0x7FFFFFFD
+#define PRT_OVF_CAP (1u << 20)  // entries of the stack-overflow list (work[513..])
 template <int STACK, bool STATS>
 PRT_DEV void traverse_ww(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t* stk, uint32_t& n_nodes,
                          uint32_t& n_tris) {
@@ -442,6 +471,7 @@ __global__ void __launch_bounds__(256) k_scan_prims(DevScene sc, const float4* _
     const uint32_t count = *count_ptr;
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < 8u) work[32u * k] = 0u;  // chunk cursors of the traversal kernel that follows on the stream (work[256]: watchdog flag)
+    if (k == 8u) work[512] = 0u;     // its overflow-list counter
     if (k >= count) return;
     const float4 O = ro[k];
     const float4 D = rd[k];
@@ -491,39 +521,61 @@ PRT_DEV uint32_t grab_chunk(uint32_t* work, uint32_t n_chunks, uint32_t my_xcd, 
     return 0xFFFFFFFFu;
 }
 
-template <int STACK_L, bool SPILL>
+// MODE 0: all entries in LDS, the host guarantees the tree never needs more than STACK_L.
+// MODE 1: LDS + global spill behind entry STACK_L (any depth; slower: the compiler merges the two address spaces
+//         into flat accesses).
+// MODE 2: all entries in LDS with an overflow check: a push beyond STACK_L sets `overflow` instead of writing; the
+//         kernel then hands that ray to the MODE-1 instance through the overflow list (never seen in practice: the
+//         host's bound is a worst case over all paths with every child hit).
+template <int STACK_L, int MODE>
 struct LaneStack {
     uint32_t* lds;      // &s_stack[threadIdx.x], stride 256
-    uint32_t* spill;    // &spill[global thread], stride n_threads (SPILL only)
+    uint32_t* spill;    // &spill[global thread], stride n_threads (MODE 1 only)
     uint32_t stride;
     int sp;
+    bool overflow;
     PRT_DEV void push(uint32_t v) {
-        if (!SPILL || sp < STACK_L)
+        if (MODE == 1) {
+            if (sp < STACK_L)
+                lds[sp * 256] = v;
+            else
+                spill[(size_t)(sp - STACK_L) * stride] = v;
+            ++sp;
+        } else if (MODE == 2) {
+            if (sp < STACK_L) {
+                lds[sp * 256] = v;
+                ++sp;
+            } else {
+                overflow = true;
+            }
+        } else {
             lds[sp * 256] = v;
-        else
-            spill[(size_t)(sp - STACK_L) * stride] = v;
-        ++sp;
+            ++sp;
+        }
     }
     // precondition: sp > 0
     PRT_DEV int pop() {
         --sp;
-        if (!SPILL || sp < STACK_L) return (int)lds[sp * 256];
+        if (MODE != 1 || sp < STACK_L) return (int)lds[sp * 256];
         return (int)spill[(size_t)(sp - STACK_L) * stride];
     }
 };
 
-template <int STACK_L, int WAVES, bool SPILL, bool STATS>
+template <int STACK_L, int WAVES, int MODE, bool STATS>
 __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
                                                                     const float* __restrict__ hd2,
                                                                     const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ work,
-                                                                    uint32_t* __restrict__ spill, PrtTravTuning tune,
+                                                                    uint32_t* __restrict__ spill,
+                                                                    const uint32_t* __restrict__ index_list,
+                                                                    uint32_t* __restrict__ ovf, PrtTravTuning tune,
                                                                     unsigned long long* __restrict__ stats) {
     __shared__ uint32_t s_stack[STACK_L * 256];
     __shared__ uint32_t s_iters[4];
-    const uint32_t count = *count_ptr;
+    uint32_t count = *count_ptr;
+    if (index_list && count > PRT_OVF_CAP) count = PRT_OVF_CAP;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
     const uint32_t my_xcd = xcc_id();
@@ -531,7 +583,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
         if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
         __syncthreads();
     }
-    LaneStack<STACK_L, SPILL> st;
+    LaneStack<STACK_L, MODE> st;
+    st.overflow = false;
     st.lds = &s_stack[threadIdx.x];
     st.stride = gridDim.x * 256u;
     st.spill = spill + (blockIdx.x * 256u + threadIdx.x);
@@ -558,7 +611,16 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
         }
         const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
         if (idle && k != 0xFFFFFFFFu) {
-            hit[k] = best.id;
+            if (MODE == 2 && st.overflow) {
+                const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable instance
+                if (j < PRT_OVF_CAP)
+                    ovf[1u + j] = k;
+                else
+                    atomicOr(work + 256, 2u);  // list full: reported by prt_synchronize like the watchdog
+                st.overflow = false;
+            } else {
+                hit[k] = best.id;
+            }
             k = 0xFFFFFFFFu;
         }
         const unsigned long long idle_mask = __ballot(idle);
@@ -576,8 +638,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
                 }
             }
             if (!exhausted) {
-                const uint32_t kk = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                if (idle && kk < cur_end) {
+                const uint32_t qi = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && qi < cur_end) {
+                    const uint32_t kk = index_list ? index_list[qi] : qi;
                     const uint32_t hid = hit[kk];
                     if (hid != HIT_DEAD) {
                         const float4 O = ro[kk];
@@ -647,6 +710,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
                 leaf = node;
                 node = (st.sp > 0) ? st.pop() : NODE_DONE;
             }
+            if (MODE == 2 && st.overflow) {  // give the ray up; it is re-traversed by the MODE-1 instance
+                node = NODE_DONE;
+                leaf = LEAF_NONE;
+                st.sp = 0;
+            }
             if ((uint32_t)__popcll(__ballot(leaf == LEAF_NONE && node != NODE_DONE)) <= tune.exit_max) break;
         }
         // ---- phase 2: leaves ----
@@ -689,18 +757,21 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse_persistent(DevScene sc,
 
 // The same kernel over the 4-wide tree (default): half as many dependent node fetches per ray, one 128-B cache
 // line per visit, children visited in entry-distance order (5-comparator sorting network).
-template <int STACK_L, int WAVES, bool SPILL, bool STATS>
+template <int STACK_L, int WAVES, int MODE, bool STATS>
 __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
                                                                     const float* __restrict__ hd2,
                                                                     const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ work,
-                                                                    uint32_t* __restrict__ spill, PrtTravTuning tune,
+                                                                    uint32_t* __restrict__ spill,
+                                                                    const uint32_t* __restrict__ index_list,
+                                                                    uint32_t* __restrict__ ovf, PrtTravTuning tune,
                                                                     unsigned long long* __restrict__ stats) {
     __shared__ uint32_t s_stack[STACK_L * 256];
     __shared__ uint32_t s_iters[4];
-    const uint32_t count = *count_ptr;
+    uint32_t count = *count_ptr;
+    if (index_list && count > PRT_OVF_CAP) count = PRT_OVF_CAP;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
     const uint32_t my_xcd = xcc_id();
@@ -708,7 +779,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
         __syncthreads();
     }
-    LaneStack<STACK_L, SPILL> st;
+    LaneStack<STACK_L, MODE> st;
+    st.overflow = false;
     st.lds = &s_stack[threadIdx.x];
     st.stride = gridDim.x * 256u;
     st.spill = spill + (blockIdx.x * 256u + threadIdx.x);
@@ -735,7 +807,16 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         }
         const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
         if (idle && k != 0xFFFFFFFFu) {
-            hit[k] = best.id;
+            if (MODE == 2 && st.overflow) {
+                const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable instance
+                if (j < PRT_OVF_CAP)
+                    ovf[1u + j] = k;
+                else
+                    atomicOr(work + 256, 2u);  // list full: reported by prt_synchronize like the watchdog
+                st.overflow = false;
+            } else {
+                hit[k] = best.id;
+            }
             k = 0xFFFFFFFFu;
         }
         const unsigned long long idle_mask = __ballot(idle);
@@ -753,8 +834,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
                 }
             }
             if (!exhausted) {
-                const uint32_t kk = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                if (idle && kk < cur_end) {
+                const uint32_t qi = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && qi < cur_end) {
+                    const uint32_t kk = index_list ? index_list[qi] : qi;
                     const uint32_t hid = hit[kk];
                     if (hid != HIT_DEAD) {
                         const float4 O = ro[kk];
@@ -838,6 +920,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
                 leaf = node;
                 node = (st.sp > 0) ? st.pop() : NODE_DONE;
             }
+            if (MODE == 2 && st.overflow) {  // give the ray up; it is re-traversed by the MODE-1 instance
+                node = NODE_DONE;
+                leaf = LEAF_NONE;
+                st.sp = 0;
+            }
             if ((uint32_t)__popcll(__ballot(leaf == LEAF_NONE && node != NODE_DONE)) <= tune.exit_max) break;
         }
         // ---- phase 2: leaves ----
@@ -898,7 +985,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // whole block exits together
     const uint32_t k = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
     if (k < 8u) work[32u * k] = 0u;  // chunk cursors of the next bounce's traversal kernel
-    bool front = false, back = false;
+    if (k == 8u) work[512] = 0u;     // its overflow-list counter
+    bool front = false, back = false, done = false;
     float4 O2, D2, T2;
     uint32_t id0 = HIT_MISS;
     float d2_0 = 3.402823466e+38f;
@@ -937,11 +1025,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
                 D2 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(rng));
                 T2 = make_float4(t2.x, t2.y, t2.z, 0.f);
                 front = classify_ray(sc, so, d2, id0, d2_0);
-                back = !front;
+                f3 L2;
+                done = ends_here(sc, front, id0, t2, L2);
+                if (done) rad[pid] = make_float4(L2.x, L2.y, L2.z, 0.f);
+                back = !front && !done;
             }
         }
     }
-    const uint32_t slot = block_alloc2(front, back, &CNT_A(counts, depth + 1u), &CNT_B(counts, depth + 1u), cap);
+    const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, depth + 1u), &CNT_B(counts, depth + 1u),
+                                       &CNT_C(counts, depth + 1u), cap);
     if (slot != 0xFFFFFFFFu) {
         no[slot] = O2;
         nd[slot] = D2;
@@ -961,7 +1053,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
                                                     uint32_t max_depth, unsigned long long* __restrict__ ray_stats) {
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
     if (pl == 0) {
-        for (uint32_t d = 0; d < max_depth; ++d) ray_stats[d] += (unsigned long long)CNT_A(counts, d) + CNT_B(counts, d);
+        for (uint32_t d = 0; d < max_depth; ++d)
+            ray_stats[d] += (unsigned long long)CNT_A(counts, d) + CNT_B(counts, d) + CNT_C(counts, d);
     }
     if (pl >= tm.n_pix_local) return;
     uint32_t x, y;
@@ -1128,45 +1221,49 @@ void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& 
                        count_ptr, work, stats);
 }
 
-void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr, uint32_t* work, uint32_t* spill, uint32_t max_rays,
-                         uint32_t tree_depth, uint32_t stack4, const PrtTravTuning& tune, unsigned long long* stats) {
+// k_fix_cursors: between the fast traversal and its overflow re-run: reset the chunk cursors.
+__global__ void k_reset_cursors(uint32_t* work) {
+    if (threadIdx.x < 8u) work[32u * threadIdx.x] = 0u;
+}
+
+void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
+                         uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
+                         const PrtTravTuning& tune, unsigned long long* stats) {
     uint32_t g = tune.grid_blocks;
-    const uint32_t need = blocks_for(max_rays);
-    if (g > need) g = need;
+    const uint32_t need_blocks = blocks_for(max_rays);
+    if (g > need_blocks) g = need_blocks;
     if (g == 0) g = 1;
     const dim3 grid(g), block(256);
-#define PRT_LAUNCH_T(L, W, SP)                                                                                        \
-    do {                                                                                                              \
-        if (stats)                                                                                                    \
-            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,  \
-                               count_ptr, work, spill, tune, stats);                                                  \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_traverse_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2, \
-                               count_ptr, work, spill, tune, stats);                                                  \
+    uint32_t* ovf = work + 512;  // [0] = count, [1..] = ray slots that overflowed the LDS stack
+    const uint32_t* no_list = nullptr;
+#define PRT_LAUNCH_T(KERNEL, L, W, MODE, GRID, COUNT, LIST)                                                        \
+    do {                                                                                                           \
+        if (stats)                                                                                                 \
+            hipLaunchKernelGGL((KERNEL<L, W, MODE, true>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,     \
+                               COUNT, work, spill, LIST, ovf, tune, stats);                                        \
+        else                                                                                                       \
+            hipLaunchKernelGGL((KERNEL<L, W, MODE, false>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,    \
+                               COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
-    // tree_depth <= stack entries in LDS: no spill code at all; deeper trees keep 31 entries in LDS + global spill
-    // a root-to-leaf path with tree_depth levels has tree_depth - 1 internal nodes = at most that many pushes
     if (tune.wide) {
-#define PRT_LAUNCH_T4(L, W, SP)                                                                                        \
-    do {                                                                                                               \
-        if (stats)                                                                                                     \
-            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, true>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,  \
-                               count_ptr, work, spill, tune, stats);                                                   \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_traverse4_persistent<L, W, SP, false>), grid, block, 0, st, sc, in.o, in.d, in.hit, in.hd2, \
-                               count_ptr, work, spill, tune, stats);                                                   \
-    } while (0)
-        if (stack4 <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T4(24, 6, false);
-        else if (stack4 <= 31) PRT_LAUNCH_T4(31, 5, false);
-        else if (stack4 <= 39 && tune.stack_lds != 31) PRT_LAUNCH_T4(39, 4, false);  // all-LDS stack, 4 blocks/CU
-        else PRT_LAUNCH_T4(31, 5, true);
-#undef PRT_LAUNCH_T4
-        return;
+        if (stack4 <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 24, 6, 0, grid, count_ptr, no_list);
+        else if (stack4 <= 31) PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 0, grid, count_ptr, no_list);
+        else if (tune.stack_lds == 39 && stack4 <= 39) PRT_LAUNCH_T(k_traverse4_persistent, 39, 4, 0, grid, count_ptr, no_list);
+        else if (tune.stack_lds == 2) {
+            // A/B: LDS-only stack with overflow check, then the spill-capable instance over the (normally empty)
+            // overflow list.  Measured equal to the always-spill instance on C3, which is therefore the default.
+            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 2, grid, count_ptr, no_list);
+            hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 1, dim3(8), ovf, ovf + 1);
+        } else {
+            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 1, grid, count_ptr, no_list);  // 31 entries in LDS + global spill
+        }
+    } else {
+        const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;
+        if (pushes <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse_persistent, 24, 6, 0, grid, count_ptr, no_list);
+        else if (pushes <= 31) PRT_LAUNCH_T(k_traverse_persistent, 31, 5, 0, grid, count_ptr, no_list);
+        else PRT_LAUNCH_T(k_traverse_persistent, 31, 5, 1, grid, count_ptr, no_list);
     }
-    const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;
-    if (pushes <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(24, 6, false);
-    else if (pushes <= 31) PRT_LAUNCH_T(31, 5, false);
-    else PRT_LAUNCH_T(31, 5, true);
 #undef PRT_LAUNCH_T
 }
 

@@ -127,6 +127,11 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
     for v in (1, 2):  # the one-thread-per-ray kernels over the binary tree give the same hits
         r.set_variant(v)
         assert util.hits_equal(r.closest_hit(o, d), want) == []
+    r.set_variant(0)
+    for name, val in (("wide", 0), ("stack_lds", 2), ("stack_lds", 39), ("xcd_affinity", 1), ("chunk", 64)):
+        r.set_param(name, val)  # every tunable / kernel instance gives the same hits
+        assert util.hits_equal(r.closest_hit(o, d), want) == [], (name, val)
+        r.set_param("wide", 1)
 
 
 def test_scatter_bit_exact_all_materials():
