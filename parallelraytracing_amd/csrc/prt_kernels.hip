@@ -100,42 +100,51 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 __device__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0);
 __device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, f3& L);
 
-__global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t n_paths,
+// All S samples of a pixel start with the same pixel-centre ray (no jitter: cpu/renderer.cpp:45), so one thread
+// computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
+// seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
+#define RAYGEN_GROUP 8
+__global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t S,
                                                             uint32_t first_sample, uint32_t seed,
                                                             float4* __restrict__ ro, float4* __restrict__ rd,
                                                             float4* __restrict__ rt, uint32_t* __restrict__ hit,
                                                             float* __restrict__ hd2, float4* __restrict__ rad,
                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ work) {
-    const uint32_t i = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
-    if (i < 8u) work[32u * i] = 0u;  // chunk cursors of the traversal kernel that follows on the stream
-    if (i == 8u) work[512] = 0u;     // its overflow-list counter
-    bool front = false, back = false, done = false;
-    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-    uint32_t rng = 0, id0 = HIT_MISS;
+    const uint32_t pl = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
+    if (blockIdx.y == 0 && pl < 8u) work[32u * pl] = 0u;  // chunk cursors of the traversal kernel that follows
+    if (blockIdx.y == 0 && pl == 8u) work[512] = 0u;      // its overflow-list counter
+    const uint32_t n_paths = S * tm.n_pix_local;
+    const bool in_range = pl < tm.n_pix_local;
+    bool valid = false, front = false, done = false;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), L = mk3(0.f, 0.f, 0.f);
+    uint32_t id0 = HIT_MISS, pixel = 0;
     float d2_0 = 3.402823466e+38f;
-    if (i < n_paths) {
-        const uint32_t s_local = i / tm.n_pix_local;
-        const uint32_t pl = i - s_local * tm.n_pix_local;
+    if (in_range) {
         uint32_t x, y;
-        if (tile_pixel(tm, pl, x, y)) {
+        valid = tile_pixel(tm, pl, x, y);
+        if (valid) {
+            pixel = y * tm.W + x;
             camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
-            rng = path_seed(y * tm.W + x, first_sample + s_local, seed);
             front = classify_ray(sc, o, d, id0, d2_0);
-            f3 L;
             done = ends_here(sc, front, id0, mk3(1.f, 1.f, 1.f), L);
-            if (done) rad[i] = make_float4(L.x, L.y, L.z, 0.f);
-            back = !front && !done;
-        } else {
-            rad[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // lanes of partial tiles outside the image: no path
         }
     }
-    const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
-    if (slot != 0xFFFFFFFFu) {
-        ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-        rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-        rt[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
-        hit[slot] = id0;
-        hd2[slot] = d2_0;
+    const bool back = valid && !front && !done;
+    const uint32_t s0 = blockIdx.y * (uint32_t)RAYGEN_GROUP;
+    const uint32_t s1 = (s0 + RAYGEN_GROUP < S) ? s0 + RAYGEN_GROUP : S;
+    for (uint32_t sl = s0; sl < s1; ++sl) {  // block-uniform trip count
+        const uint32_t i = sl * tm.n_pix_local + pl;  // path id
+        // paths that end here (sky / light seen directly) and lanes of partial tiles outside the image: rad only
+        if (in_range && (!valid || done)) rad[i] = make_float4(L.x, L.y, L.z, 0.f);
+        const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
+        if (slot != 0xFFFFFFFFu) {
+            const uint32_t rng = path_seed(pixel, first_sample + sl, seed);
+            ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+            rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
+            rt[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+            hit[slot] = id0;
+            hd2[slot] = d2_0;
+        }
     }
 }
 
@@ -1211,8 +1220,10 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 2
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
                        uint32_t* work) {
-    hipLaunchKernelGGL(k_raygen, dim3((n_paths + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK), dim3(PRODUCER_BLOCK), 0, st, sc,
-                       cam, tm, n_paths, first_sample, seed, out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work);
+    const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
+    const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
+    hipLaunchKernelGGL(k_raygen, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o, out.d,
+                       out.t, out.hit, out.hd2, rad, counts, work);
 }
 
 void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
