@@ -136,6 +136,8 @@ typedef struct PrtStats {
     uint64_t node_lane_slots;          /* 64 x node-loop iterations of all waves: visits / slots = lane efficiency */
     double scan_ms;                    /* analytic-primitive scan kernel (function-level entry points only) */
     uint64_t rays_traversed;           /* prt_measure_traversal: rays that entered the BVH root box (walked the tree) */
+    uint64_t tri_lane_slots;           /* 64 x triangle-loop iterations of all waves: tri tests / slots = lane efficiency */
+    uint64_t max_stack_used;           /* deepest traversal stack any ray reached (prt_measure_traversal) */
 } PrtStats;
 
 typedef struct PrtBvhInfo {

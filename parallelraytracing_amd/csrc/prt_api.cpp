@@ -87,7 +87,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
-    PrtTravTuning tune{1280u, 256u, 16u, 16u, 0u, 1u, 31u};  // XCD affinity measured 7 % slower on C3 (uneven eighths)  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
+    PrtTravTuning tune{1024u, 256u, 32u, 8u, 0u, 1u, 0u};  // grid 256 CUs x 4 blocks; stack_lds 0 = default instance  // XCD affinity measured 7 % slower on C3 (uneven eighths)  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -167,10 +167,10 @@ int ensure_counters(PrtContext* c) {
     if (c->d_counts) return PRT_OK;
     HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 4 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 8 * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 8 * sizeof(unsigned long long)));
     // [0..255] chunk cursors (one 128-B line per XCD), [256] watchdog flag, [512] overflow count, [513..] overflow list
     HIPCHECK(c, hipMalloc((void**)&c->d_work, (513 + (1u << 20)) * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_work, 0, (513 + (1u << 20)) * sizeof(uint32_t)));
@@ -843,7 +843,7 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     if (rc) return rc;
     if (!out || max_depth == 0 || max_depth > PRT_MAX_DEPTH) return fail(c, PRT_ERR_INVALID, "bad arguments");
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 4 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 8 * sizeof(unsigned long long)));
     const bool timing = c->timing;
     const uint64_t launches = c->stats.intersect_launches;
     c->timing = false;
@@ -852,7 +852,7 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     c->stats.intersect_launches = launches;
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    unsigned long long t[4];
+    unsigned long long t[8];
     std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
     HIPCHECK(c, hipMemcpy(cnt.data(), c->d_counts, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -871,6 +871,8 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     out->bvh_tri_tests = t[1];
     out->prim_tests = (uint64_t)c->prims.size() * out->rays_total;  // every ray scans every analytic primitive
     out->node_lane_slots = t[3];
+    out->tri_lane_slots = t[4];
+    out->max_stack_used = t[5];
     return PRT_OK;
 }
 
@@ -904,7 +906,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1)) c->tune.wide = (uint32_t)value;
-    else if (n == "stack_lds" && (value == 2 || value == 24 || value == 31 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
     else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;
     else return fail(c, PRT_ERR_INVALID, "unknown parameter or bad value: %s = %d", name, value);

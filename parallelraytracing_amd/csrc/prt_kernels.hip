@@ -318,6 +318,7 @@ PRT_DEV void traverse_ifif(const DevScene& sc, f3 o, f3 d, Closest& best, uint32
 // leaves the node loop only when no lane is still searching (one ballot per step), and then all lanes test
 // their leaves together.  Node steps and triangle tests are therefore executed with far fewer idle lanes
 // than the one-loop form, where the two code paths alternate within a wave.
+typedef float v2f __attribute__((ext_vector_type(2)));
 #define NODE_DONE 0x7FFFFFFF
 #define LEAF_NONE 0x7FFFFFFE
 #define NEED_POP 0x7FFFFFFD
@@ -777,15 +778,17 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
                                                                     const uint32_t* __restrict__ index_list,
                                                                     uint32_t* __restrict__ ovf, PrtTravTuning tune,
                                                                     unsigned long long* __restrict__ stats) {
-    __shared__ uint32_t s_stack[STACK_L * 256];
-    __shared__ uint32_t s_iters[4];
+    __shared__ uint32_t s_stack[(STACK_L + (MODE == 3 ? 3 : 0)) * 256];  // MODE 3 writes up to 3 rows past the top
+    __shared__ unsigned long long s_key[256];  // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
+    __shared__ uint32_t s_slot[256];           // per lane: leaf-order slot of that best
+    __shared__ uint32_t s_iters[8];  // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
     uint32_t count = *count_ptr;
     if (index_list && count > PRT_OVF_CAP) count = PRT_OVF_CAP;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
     const uint32_t my_xcd = xcc_id();
     if (STATS) {
-        if (threadIdx.x < 4) s_iters[threadIdx.x] = 0;
+        if (threadIdx.x < 8) s_iters[threadIdx.x] = 0;
         __syncthreads();
     }
     LaneStack<STACK_L, MODE> st;
@@ -803,7 +806,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
     best.d2 = 3.402823466e+38f;
     best.id = HIT_MISS;
     best.prim = 0xFFFFFFFFu;
-    uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t n_nodes = 0, n_tris = 0, max_sp = 0;
     uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
     bool exhausted = false;         // wave-uniform
     // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
@@ -816,7 +819,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         }
         const bool idle = (node == NODE_DONE) && (leaf == LEAF_NONE);
         if (idle && k != 0xFFFFFFFFu) {
-            if (MODE == 2 && st.overflow) {
+            if ((MODE == 2 || MODE == 3) && st.overflow) {
                 const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable instance
                 if (j < PRT_OVF_CAP)
                     ovf[1u + j] = k;
@@ -877,6 +880,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         }
         // ---- phase 1: internal nodes (leave when at most exit_max lanes are still looking for a leaf) ----
         while ((unsigned)node < 0x40000000u) {
+            const int sp0 = st.sp;
+            int t1 = 0, t2 = 0;
+            if (MODE == 3) {  // the two entries under the top, read before anything is written this step
+                t1 = (int)st.lds[(sp0 > 0 ? sp0 - 1 : 0) * 256];
+                t2 = (int)st.lds[(sp0 > 1 ? sp0 - 2 : 0) * 256];
+            }
             const float4* nb = sc.nodes4 + 8 * (size_t)node;
             const float4 mnx = nb[0], mxx = nb[1], mny = nb[2], mxy = nb[3], mnz = nb[4], mxz = nb[5], rf = nb[6];
             if (STATS) {
@@ -885,22 +894,31 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
             }
             const float kInf = __builtin_inff();
             float k0, k1, k2, k3;
-#define PRT_CHILD(C, KEY)                                                                                          \
-    {                                                                                                              \
-        const float x0 = __builtin_fmaf(mnx.C, ix, -ax), x1 = __builtin_fmaf(mxx.C, ix, -bx);                      \
-        const float y0 = __builtin_fmaf(mny.C, iy, -ay), y1 = __builtin_fmaf(mxy.C, iy, -by);                      \
-        const float z0 = __builtin_fmaf(mnz.C, iz, -az), z1 = __builtin_fmaf(mxz.C, iz, -bz);                      \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),        \
-                                         __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));                          \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),        \
-                                         __builtin_fminf(__builtin_fmaxf(z0, z1), tlimit));                        \
-        KEY = (tn <= tf * 1.0000005f) ? tn : kInf;                                                                 \
+            // children are tested two at a time with packed FMAs (v_pk_fma_f32: two independent fp32 FMAs, the same
+            // rounding as the scalar form); min/max have no packed fp32 form
+#define PRT_PAIR(LO, HI, KA, KB)                                                                                    \
+    {                                                                                                               \
+        const v2f x0 = __builtin_elementwise_fma((v2f){mnx.LO, mnx.HI}, (v2f){ix, ix}, (v2f){-ax, -ax});            \
+        const v2f x1 = __builtin_elementwise_fma((v2f){mxx.LO, mxx.HI}, (v2f){ix, ix}, (v2f){-bx, -bx});            \
+        const v2f y0 = __builtin_elementwise_fma((v2f){mny.LO, mny.HI}, (v2f){iy, iy}, (v2f){-ay, -ay});            \
+        const v2f y1 = __builtin_elementwise_fma((v2f){mxy.LO, mxy.HI}, (v2f){iy, iy}, (v2f){-by, -by});            \
+        const v2f z0 = __builtin_elementwise_fma((v2f){mnz.LO, mnz.HI}, (v2f){iz, iz}, (v2f){-az, -az});            \
+        const v2f z1 = __builtin_elementwise_fma((v2f){mxz.LO, mxz.HI}, (v2f){iz, iz}, (v2f){-bz, -bz});            \
+        const float tna = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0.x, x1.x), __builtin_fminf(y0.x, y1.x)), \
+                                          __builtin_fmaxf(__builtin_fminf(z0.x, z1.x), 0.0f));                       \
+        const float tfa = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0.x, x1.x), __builtin_fmaxf(y0.x, y1.x)), \
+                                          __builtin_fminf(__builtin_fmaxf(z0.x, z1.x), tlimit));                     \
+        const float tnb = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0.y, x1.y), __builtin_fminf(y0.y, y1.y)), \
+                                          __builtin_fmaxf(__builtin_fminf(z0.y, z1.y), 0.0f));                       \
+        const float tfb = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0.y, x1.y), __builtin_fmaxf(y0.y, y1.y)), \
+                                          __builtin_fminf(__builtin_fmaxf(z0.y, z1.y), tlimit));                     \
+        const v2f tfs = (v2f){tfa, tfb} * (v2f){1.0000005f, 1.0000005f};                                             \
+        KA = (tna <= tfs.x) ? tna : kInf;                                                                           \
+        KB = (tnb <= tfs.y) ? tnb : kInf;                                                                           \
     }
-            PRT_CHILD(x, k0)
-            PRT_CHILD(y, k1)
-            PRT_CHILD(z, k2)
-            PRT_CHILD(w, k3)
-#undef PRT_CHILD
+            PRT_PAIR(x, y, k0, k1)
+            PRT_PAIR(z, w, k2, k3)
+#undef PRT_PAIR
             int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
             // sort the four (entry distance, ref) pairs ascending: 5-comparator network; misses (+inf) end up last
 #define PRT_CSWAP(KA, RA, KB, RB)            \
@@ -919,6 +937,31 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
             PRT_CSWAP(k1, r1, k3, r3)
             PRT_CSWAP(k1, r1, k2, r2)
 #undef PRT_CSWAP
+            if (MODE == 3) {
+                // Branch-free step.  The three far children are stored unconditionally above the top (farthest
+                // first) and the stack pointer advances only past the ones that were hit; the two entries below
+                // the old top were read into t1/t2 at the head of the step, so "next node" and "postpone a leaf"
+                // are pure selects.  A step that would leave more than STACK_L entries gives the ray up (it is
+                // re-traversed by the spill-capable instance through the overflow list).
+                const int h0 = k0 < kInf, h1 = k1 < kInf, h2 = k2 < kInf, h3 = k3 < kInf;
+                st.lds[sp0 * 256] = (uint32_t)r3;
+                const int s1 = sp0 + h3;
+                st.lds[s1 * 256] = (uint32_t)r2;
+                const int s2 = s1 + h2;
+                st.lds[s2 * 256] = (uint32_t)r1;
+                const int sp1 = s2 + h1;
+                const int below0 = sp0 > 0 ? t1 : NODE_DONE;  // top of the stack before this step
+                const int below1 = sp0 > 1 ? t2 : NODE_DONE;  // the entry under it
+                const int nxt = h0 ? r0 : below0;
+                const int spn = h0 ? sp1 : (sp0 > 0 ? sp0 - 1 : 0);
+                const bool take = (nxt < 0) && (leaf == LEAF_NONE);  // first leaf: postpone it, keep walking
+                const int under = h0 ? (h1 ? r1 : below0) : below1;
+                const int spu = h0 ? (h1 ? sp1 - 1 : (sp0 > 0 ? sp0 - 1 : 0)) : (sp0 > 1 ? sp0 - 2 : 0);
+                leaf = take ? nxt : leaf;
+                node = take ? under : nxt;
+                st.sp = take ? spu : spn;
+                if (sp1 > STACK_L) st.overflow = true;
+            } else {
             // farthest first, so that the nearest pending child is popped first
             if (k3 < kInf) st.push((uint32_t)r3);
             if (k2 < kInf) st.push((uint32_t)r2);
@@ -929,40 +972,106 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
                 leaf = node;
                 node = (st.sp > 0) ? st.pop() : NODE_DONE;
             }
-            if (MODE == 2 && st.overflow) {  // give the ray up; it is re-traversed by the MODE-1 instance
+            }
+            if ((MODE == 2 || MODE == 3) && st.overflow) {  // give the ray up; it is re-traversed by the MODE-1 instance
                 node = NODE_DONE;
                 leaf = LEAF_NONE;
                 st.sp = 0;
             }
+            if (STATS && (uint32_t)st.sp > max_sp) max_sp = (uint32_t)st.sp;
             if ((uint32_t)__popcll(__ballot(leaf == LEAF_NONE && node != NODE_DONE)) <= tune.exit_max) break;
         }
-        // ---- phase 2: leaves ----
-        while (leaf != LEAF_NONE) {
-            const uint32_t ref = ~(uint32_t)leaf;
-            const uint32_t first = ref >> 4, cnt = ref & 15u;
-            for (uint32_t t = 0; t < cnt; ++t) {
-                const uint32_t slot = first + t;
-                const float4 a = sc.tris[3 * (size_t)slot + 0];
-                const float4 b = sc.tris[3 * (size_t)slot + 1];
-                const float4 c = sc.tris[3 * (size_t)slot + 2];
-                if (STATS) ++n_tris;
-                f3 pos;
-                float b1, b2;
-                if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, ld, pos, b1, b2)) {
-                    const float d2 = dist2(o, pos);
-                    const uint32_t prim = __float_as_uint(a.w);
-                    if (d2 < best.d2 || (d2 == best.d2 && best.id != HIT_MISS && prim < best.prim)) {
-                        best.d2 = d2;
-                        best.id = sc.n_prims + slot;
-                        best.prim = prim;
-                        tlimit = limit_from_d2(d2, pad);
-                    }
-                }
+        // ---- phase 2: leaves, tested COOPERATIVELY by the wave ----
+        // A lane holds 0..2 pending leaves (the postponed one and, if the walk stopped on a second leaf, that one)
+        // = 0..8 triangles.  Testing them lane by lane leaves 86 % of the lanes idle (measured), so the wave pools
+        // all pending (ray, triangle) pairs and every lane tests ONE pair per round: the pair's owner lane is found
+        // by a 6-step search over the running offsets, the owner's ray comes over ds_bpermute, and the results are
+        // merged per owner with a 64-bit LDS atomicMin on (d2 bits << 32 | primitive index) -- exactly the
+        // reference's rule "smaller d2 wins, ties to the lower primitive index" (primitive.cpp:42-48), since d2 >= 0
+        // makes the float order equal to the integer order of its bits.
+        {
+            const bool second = node < 0;  // NODE_DONE / internal ids are >= 0
+            uint32_t f1 = 0, c1 = 0, f2 = 0, c2 = 0;
+            if (leaf != LEAF_NONE) {
+                const uint32_t ref = ~(uint32_t)leaf;
+                f1 = ref >> 4;
+                c1 = ref & 15u;
             }
-            leaf = LEAF_NONE;
-            if (node < 0) {  // the walk stopped on a second leaf: take it now
-                leaf = node;
-                node = (st.sp > 0) ? st.pop() : NODE_DONE;
+            if (second) {
+                const uint32_t ref = ~(uint32_t)node;
+                f2 = ref >> 4;
+                c2 = ref & 15u;
+            }
+            const uint32_t total = c1 + c2;
+            if (__ballot(total != 0u) != 0ull) {  // wave-uniform
+                // inclusive scan of `total` over the wave
+                uint32_t incl = total;
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
+                    if ((int)lane >= sh) incl += up;
+                }
+                const uint32_t off = incl - total;
+                const uint32_t T = (uint32_t)__shfl((int)incl, 63, 64);
+                // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
+                const unsigned long long key_best =
+                    ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
+                const uint32_t my = threadIdx.x;             // this lane's LDS cell
+                const uint32_t wbase = threadIdx.x & ~63u;  // first cell of this wave
+                s_key[my] = key_best;
+                for (uint32_t base = 0; base < T; base += 64u) {  // wave-uniform trip count
+                    const uint32_t kq = base + lane;
+                    uint32_t owner = 0;
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        const uint32_t pr = owner + (uint32_t)step;
+                        const uint32_t op = (uint32_t)__shfl((int)off, (int)(pr & 63u), 64);
+                        if (pr < 64u && op <= kq) owner = pr;
+                    }
+                    const uint32_t ooff = (uint32_t)__shfl((int)off, (int)owner, 64);
+                    const uint32_t oc1 = (uint32_t)__shfl((int)c1, (int)owner, 64);
+                    const uint32_t of1 = (uint32_t)__shfl((int)f1, (int)owner, 64);
+                    const uint32_t of2 = (uint32_t)__shfl((int)f2, (int)owner, 64);
+                    const f3 qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
+                    const f3 qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                    bool cand = false;
+                    unsigned long long key = 0ull;
+                    uint32_t slot = 0;
+                    if (kq < T) {
+                        const uint32_t j = kq - ooff;
+                        slot = j < oc1 ? of1 + j : of2 + (j - oc1);
+                        const float4 a = sc.tris[3 * (size_t)slot + 0];
+                        const float4 b = sc.tris[3 * (size_t)slot + 1];
+                        const float4 c = sc.tris[3 * (size_t)slot + 2];
+                        if (STATS) ++n_tris;
+                        f3 pos;
+                        float b1, b2;
+                        if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), qo, qd, pos, b1, b2)) {
+                            const float d2 = dist2(qo, pos);
+                            key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(a.w);
+                            // NaN / inf d2 have bit patterns above FLT_MAX's: they can never win, as in the reference
+                            cand = true;
+                            atomicMin(&s_key[wbase + owner], key);
+                        }
+                    }
+                    if (STATS && lane == 0) ++s_iters[4 + (threadIdx.x >> 6)];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = slot;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                const unsigned long long won = ((volatile unsigned long long*)s_key)[my];
+                if (won != key_best) {
+                    best.d2 = __uint_as_float((uint32_t)(won >> 32));
+                    best.prim = (uint32_t)won;
+                    best.id = sc.n_prims + ((volatile uint32_t*)s_slot)[my];
+                    tlimit = limit_from_d2(best.d2, pad);
+                }
+                leaf = LEAF_NONE;
+                if (second) node = (st.sp > 0) ? st.pop() : NODE_DONE;
+                if (node < 0) {  // a popped leaf: postpone it (and a second one stays in `node`)
+                    leaf = node;
+                    node = (st.sp > 0) ? st.pop() : NODE_DONE;
+                }
             }
         }
     }
@@ -971,6 +1080,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         atomicAdd(&stats[1], (unsigned long long)n_tris);
         __syncthreads();
         if (threadIdx.x < 4) atomicAdd(&stats[3], 64ull * s_iters[threadIdx.x]);
+        if (threadIdx.x < 4) atomicAdd(&stats[4], 64ull * s_iters[4 + threadIdx.x]);
+        atomicMax(&stats[5], (unsigned long long)max_sp);
     }
 }
 
@@ -1257,17 +1368,30 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
     if (tune.wide) {
-        if (stack4 <= 24 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 24, 6, 0, grid, count_ptr, no_list);
-        else if (stack4 <= 31) PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 0, grid, count_ptr, no_list);
-        else if (tune.stack_lds == 39 && stack4 <= 39) PRT_LAUNCH_T(k_traverse4_persistent, 39, 4, 0, grid, count_ptr, no_list);
+        if (stack4 <= 23 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 23, 6, 0, grid, count_ptr, no_list);
+        else if (stack4 <= 28) PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 0, grid, count_ptr, no_list);
+        else if (tune.stack_lds == 39 && stack4 <= 36) PRT_LAUNCH_T(k_traverse4_persistent, 36, 4, 0, grid, count_ptr, no_list);
         else if (tune.stack_lds == 2) {
             // A/B: LDS-only stack with overflow check, then the spill-capable instance over the (normally empty)
             // overflow list.  Measured equal to the always-spill instance on C3, which is therefore the default.
-            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 2, grid, count_ptr, no_list);
+            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 2, grid, count_ptr, no_list);
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
-            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 1, dim3(8), ovf, ovf + 1);
+            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
+        } else if (tune.stack_lds == 3) {
+            // branch-free node step on an LDS-only stack of 25 entries (+3 rows of slack), overflow list -> MODE 1
+            PRT_LAUNCH_T(k_traverse4_persistent, 25, 5, 3, grid, count_ptr, no_list);
+            hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
+        } else if (tune.stack_lds == 1) {
+            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, grid, count_ptr, no_list);  // A/B: 28 entries in LDS + global spill
         } else {
-            PRT_LAUNCH_T(k_traverse4_persistent, 31, 5, 1, grid, count_ptr, no_list);  // 31 entries in LDS + global spill
+            // default: branch-free node step, LDS-only stack of 33 entries (the deepest stack any C3 ray reaches is 17;
+            // the host's worst-case bound is 36), 4 waves/SIMD so that the 116 VGPRs need no scratch (the 5-wave
+            // instances spill 50-70 B/lane and are 9 % slower); a ray that would overflow goes to the overflow list
+            // and is re-traversed by the spill-capable instance.
+            PRT_LAUNCH_T(k_traverse4_persistent, 33, 4, 3, grid, count_ptr, no_list);
+            hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
         }
     } else {
         const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;

@@ -128,7 +128,7 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
         r.set_variant(v)
         assert util.hits_equal(r.closest_hit(o, d), want) == []
     r.set_variant(0)
-    for name, val in (("wide", 0), ("stack_lds", 2), ("stack_lds", 39), ("xcd_affinity", 1), ("chunk", 64)):
+    for name, val in (("wide", 0), ("stack_lds", 1), ("stack_lds", 2), ("stack_lds", 3), ("stack_lds", 39), ("xcd_affinity", 1), ("chunk", 64)):
         r.set_param(name, val)  # every tunable / kernel instance gives the same hits
         assert util.hits_equal(r.closest_hit(o, d), want) == [], (name, val)
         r.set_param("wide", 1)

@@ -10,7 +10,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-DEFAULTS = {"variant": 0, "grid_blocks": 1280, "chunk": 256, "refill_min": 16, "exit_max": 16, "xcd_affinity": 0, "wide": 1, "stack_lds": 31}
+DEFAULTS = {"variant": 0, "grid_blocks": 1024, "chunk": 256, "refill_min": 32, "exit_max": 8, "xcd_affinity": 0, "wide": 1, "stack_lds": 0}
 
 
 def main():
@@ -87,6 +87,7 @@ def main():
             apply(d)
             tr = r.measure_traversal()
             line += (f"  eff {tr.bvh_node_visits / max(1, tr.node_lane_slots):.3f} walked {tr.rays_traversed / tr.rays_total:.3f}"
+                     f" tri-eff {tr.bvh_tri_tests / max(1, tr.tri_lane_slots):.3f} maxsp {tr.max_stack_used}"
                      f" nodes/walked {tr.bvh_node_visits / max(1, tr.rays_traversed):.2f} tris/walked {tr.bvh_tri_tests / max(1, tr.rays_traversed):.2f}")
         print(line, flush=True)
 
