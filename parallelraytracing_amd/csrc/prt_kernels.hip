@@ -537,6 +537,30 @@ PRT_DEV uint32_t grab_chunk(uint32_t* work, uint32_t n_chunks, uint32_t my_xcd, 
 // MODE 2: all entries in LDS with an overflow check: a push beyond STACK_L sets `overflow` instead of writing; the
 //         kernel then hands that ray to the MODE-1 instance through the overflow list (never seen in practice: the
 //         host's bound is a worst case over all paths with every child hit).
+// Wave64 inclusive scans with DPP row shifts / row broadcasts (no LDS round trips): the Hillis-Steele steps
+// 1, 2, 4, 8 inside each 16-lane row, then lane 15 of rows 0/2 into rows 1/3 and lane 31 into rows 2/3.  Lanes that
+// receive nothing keep the identity (0).  All 64 lanes must be active.
+#define PRT_DPP(X, CTRL, ROWMASK) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(X), CTRL, ROWMASK, 0xF, false)
+PRT_DEV uint32_t wave_scan_add(uint32_t x) {
+    x += PRT_DPP(x, 0x111, 0xF);  // row_shr:1
+    x += PRT_DPP(x, 0x112, 0xF);  // row_shr:2
+    x += PRT_DPP(x, 0x114, 0xF);  // row_shr:4
+    x += PRT_DPP(x, 0x118, 0xF);  // row_shr:8
+    x += PRT_DPP(x, 0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+    x += PRT_DPP(x, 0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+PRT_DEV uint32_t wave_scan_max(uint32_t x) {
+    uint32_t t;
+    t = PRT_DPP(x, 0x111, 0xF); x = x > t ? x : t;
+    t = PRT_DPP(x, 0x112, 0xF); x = x > t ? x : t;
+    t = PRT_DPP(x, 0x114, 0xF); x = x > t ? x : t;
+    t = PRT_DPP(x, 0x118, 0xF); x = x > t ? x : t;
+    t = PRT_DPP(x, 0x142, 0xA); x = x > t ? x : t;
+    t = PRT_DPP(x, 0x143, 0xC); x = x > t ? x : t;
+    return x;
+}
+
 template <int STACK_L, int MODE>
 struct LaneStack {
     uint32_t* lds;      // &s_stack[threadIdx.x], stride 256
@@ -781,6 +805,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
     __shared__ uint32_t s_stack[(STACK_L + (MODE == 3 ? 3 : 0)) * 256];  // MODE 3 writes up to 3 rows past the top
     __shared__ unsigned long long s_key[256];  // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
     __shared__ uint32_t s_slot[256];           // per lane: leaf-order slot of that best
+    __shared__ uint32_t s_mark[256];           // per item position of a round: owner lane + 1 where an owner's range starts
     __shared__ uint32_t s_iters[8];  // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
     uint32_t count = *count_ptr;
     if (index_list && count > PRT_OVF_CAP) count = PRT_OVF_CAP;
@@ -1004,30 +1029,28 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
             }
             const uint32_t total = c1 + c2;
             if (__ballot(total != 0u) != 0ull) {  // wave-uniform
-                // inclusive scan of `total` over the wave
-                uint32_t incl = total;
-#pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
-                    if ((int)lane >= sh) incl += up;
-                }
+                const uint32_t incl = wave_scan_add(total);
                 const uint32_t off = incl - total;
-                const uint32_t T = (uint32_t)__shfl((int)incl, 63, 64);
+                const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
                 const unsigned long long key_best =
                     ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
                 const uint32_t my = threadIdx.x;             // this lane's LDS cell
                 const uint32_t wbase = threadIdx.x & ~63u;  // first cell of this wave
                 s_key[my] = key_best;
+                uint32_t carry = 0;  // wave-uniform
                 for (uint32_t base = 0; base < T; base += 64u) {  // wave-uniform trip count
                     const uint32_t kq = base + lane;
-                    uint32_t owner = 0;
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) {
-                        const uint32_t pr = owner + (uint32_t)step;
-                        const uint32_t op = (uint32_t)__shfl((int)off, (int)(pr & 63u), 64);
-                        if (pr < 64u && op <= kq) owner = pr;
-                    }
+                    // owner of item kq: every owner whose range starts inside this round marks its first position,
+                    // a max-scan spreads the marks to the right; positions before the first mark continue the last
+                    // owner of the previous round
+                    s_mark[my] = 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (total != 0u && off >= base && off < base + 64u) s_mark[wbase + (off - base)] = lane + 1u;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    const uint32_t mk = wave_scan_max(((volatile uint32_t*)s_mark)[my]);
+                    const uint32_t owner = mk ? mk - 1u : carry;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)owner, 63);
                     const uint32_t ooff = (uint32_t)__shfl((int)off, (int)owner, 64);
                     const uint32_t oc1 = (uint32_t)__shfl((int)c1, (int)owner, 64);
                     const uint32_t of1 = (uint32_t)__shfl((int)f1, (int)owner, 64);
@@ -1368,30 +1391,30 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
     if (tune.wide) {
-        if (stack4 <= 23 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 23, 6, 0, grid, count_ptr, no_list);
-        else if (stack4 <= 28) PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 0, grid, count_ptr, no_list);
-        else if (tune.stack_lds == 39 && stack4 <= 36) PRT_LAUNCH_T(k_traverse4_persistent, 36, 4, 0, grid, count_ptr, no_list);
+        if (stack4 <= 22 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 22, 6, 0, grid, count_ptr, no_list);
+        else if (stack4 <= 27) PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 0, grid, count_ptr, no_list);
+        else if (tune.stack_lds == 39 && stack4 <= 35) PRT_LAUNCH_T(k_traverse4_persistent, 35, 4, 0, grid, count_ptr, no_list);
         else if (tune.stack_lds == 2) {
             // A/B: LDS-only stack with overflow check, then the spill-capable instance over the (normally empty)
             // overflow list.  Measured equal to the always-spill instance on C3, which is therefore the default.
-            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 2, grid, count_ptr, no_list);
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 2, grid, count_ptr, no_list);
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
-            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
         } else if (tune.stack_lds == 3) {
             // branch-free node step on an LDS-only stack of 25 entries (+3 rows of slack), overflow list -> MODE 1
-            PRT_LAUNCH_T(k_traverse4_persistent, 25, 5, 3, grid, count_ptr, no_list);
+            PRT_LAUNCH_T(k_traverse4_persistent, 24, 5, 3, grid, count_ptr, no_list);
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
-            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
         } else if (tune.stack_lds == 1) {
-            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, grid, count_ptr, no_list);  // A/B: 28 entries in LDS + global spill
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, grid, count_ptr, no_list);  // A/B: 28 entries in LDS + global spill
         } else {
-            // default: branch-free node step, LDS-only stack of 33 entries (the deepest stack any C3 ray reaches is 17;
+            // default: branch-free node step, LDS-only stack of 32 entries (the deepest stack any C3 ray reaches is 17;
             // the host's worst-case bound is 36), 4 waves/SIMD so that the 116 VGPRs need no scratch (the 5-wave
             // instances spill 50-70 B/lane and are 9 % slower); a ray that would overflow goes to the overflow list
             // and is re-traversed by the spill-capable instance.
-            PRT_LAUNCH_T(k_traverse4_persistent, 33, 4, 3, grid, count_ptr, no_list);
+            PRT_LAUNCH_T(k_traverse4_persistent, 32, 4, 3, grid, count_ptr, no_list);
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
-            PRT_LAUNCH_T(k_traverse4_persistent, 28, 5, 1, dim3(8), ovf, ovf + 1);
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
         }
     } else {
         const uint32_t pushes = tree_depth ? tree_depth - 1u : 0u;
