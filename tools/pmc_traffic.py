@@ -24,13 +24,19 @@ args = ap.parse_args()
 
 
 def total(d, counter):
-    s, n = 0.0, set()
+    """Counter sum and dispatch count of the DOMINANT instance of the kernel (the template instance with the
+    largest sum: the overflow-list re-traversal and the instrumented instance are separate, tiny dispatches)."""
+    s, n = collections.Counter(), collections.defaultdict(set)
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if args.kernel in r["Kernel_Name"] and r["Counter_Name"] == counter and "true>" not in r["Kernel_Name"].split("(")[0]:
-                s += float(r["Counter_Value"])
-                n.add(r["Dispatch_Id"])
-    return s, len(n)
+            name = r["Kernel_Name"].split("(")[0]
+            if args.kernel in name and r["Counter_Name"] == counter and "true>" not in name:
+                s[name] += float(r["Counter_Value"])
+                n[name].add(r["Dispatch_Id"])
+    if not s:
+        return 0.0, 0
+    main = max(s, key=lambda k: s[k])
+    return s[main], len(n[main])
 
 
 fetch, n1 = total(args.fetch_dir, "FETCH_SIZE")
