@@ -27,7 +27,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-NODE_BYTES = 128       # one BVH4 node visit: four child AABBs + four child refs = one cache line (csrc/bvh.h)
+NODE_BYTES = 80        # one compressed 8-wide node visit: origin + exponents + 8 x (6 quantized planes + meta) (csrc/bvh.h)
+NODE_BYTES4 = 128      # one BVH4 node visit (A/B kernels): four child AABBs + four child refs = one cache line
 TRI_BYTES = 48         # one leaf triangle test: 3 x float4 (P0+prim, P1+material, P2)
 RAY_FIXED_BYTES = 44   # traversal kernel per ray it walks: origin+dir (2 x 16 B) + hit id and d2 read (8 B) + hit id write (4 B)
 PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
@@ -60,6 +61,7 @@ def parse():
     ap.add_argument("--spp-per-step", type=int, default=0, help="0 = the config's full sample count (C3: 256)")
     ap.add_argument("--samples-in-flight", type=int, default=0, help="0 = auto")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--wide", type=int, default=2, help="2 = compressed 8-wide tree (default), 1 = 4-wide tree (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -104,6 +106,7 @@ def main():
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.Init(film, scene, cam)
     r.set_variant(args.variant)
+    r.set_param("wide", args.wide)
     n_tris = scene.n_triangles
     bvh = r.bvh_info()
     spp_step = args.spp_per_step or spp_total  # a step = one complete frame of the config
@@ -119,7 +122,10 @@ def main():
     trav = r.measure_traversal(sample=0)
     rays_sample = int(trav.rays_total)
     rays_walked = int(trav.rays_traversed)  # rays that enter the BVH root box; the others never reach this kernel
-    alg_bytes_sample = (NODE_BYTES * int(trav.bvh_node_visits) + TRI_BYTES * int(trav.bvh_tri_tests)
+    wide8 = int(bvh.n_nodes8) > 0 and args.wide == 2
+    node_bytes = NODE_BYTES if wide8 else NODE_BYTES4
+    kernel_name = "k_traverse8_persistent" if wide8 else "k_traverse4_persistent"
+    alg_bytes_sample = (node_bytes * int(trav.bvh_node_visits) + TRI_BYTES * int(trav.bvh_tri_tests)
                         + RAY_FIXED_BYTES * rays_walked)
 
     def step():
@@ -175,7 +181,7 @@ def main():
         traffic, traffic_note = load_traffic(args.config, world, spp_step, sif)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": "k_traverse4_persistent",
+                    "kernel": kernel_name, "node_bytes": node_bytes,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
                     "alg_bytes_per_launch": int(bytes_per_launch),
                     "rays_walked_frac": round(rays_walked / max(1, rays_sample), 3),
@@ -242,6 +248,7 @@ def main():
                                    f"{spp_step} spp per step ({args.steps * spp_step} spp timed of the config's {spp_total}), "
                                    f"image tiled over {world} GPU(s) + per-step gather to rank 0",
                        "triangles": n_tris, "bvh_nodes": int(bvh.n_nodes), "bvh_max_depth": int(bvh.max_depth),
+                       "bvh8_nodes": int(bvh.n_nodes8), "bvh8_depth": int(bvh.depth8),
                        "width": W, "height": H, "max_depth": max_depth, "spp_per_step": spp_step,
                        "samples_in_flight": sif, "seed": 0, "rays_timed": rays_total,
                        "rays_per_sample": rays_sample, "setup_s": round(setup_s, 2), "variant": args.variant},

@@ -151,6 +151,8 @@ typedef struct PrtBvhInfo {
     uint64_t tri_bytes;
     uint32_t n_nodes4;     /* 4-wide nodes (128 B each) */
     uint32_t max_stack4;   /* worst-case traversal stack entries of the 4-wide tree */
+    uint32_t n_nodes8;     /* compressed 8-wide nodes (80 B each) the default kernel walks; 0 = not available */
+    uint32_t depth8;       /* levels of the 8-wide tree (the traversal stacks at most depth8 - 1 node groups) */
 } PrtBvhInfo;
 
 typedef struct PrtContext PrtContext;
@@ -225,9 +227,12 @@ int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
 int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);
 /* The 4-wide tree: n_nodes4*32 floats (layout: csrc/bvh.h). */
 int prt_bvh_read4(PrtContext* ctx, float* nodes4);
+/* The compressed 8-wide tree: n_nodes8*20 uint32 (layout: csrc/bvh.h). */
+int prt_bvh_read8(PrtContext* ctx, uint32_t* nodes8);
 /* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
 int prt_set_variant(PrtContext* ctx, int variant);
-/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "wide", "stack_lds". */
+/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "wide" (2 = compressed
+ * 8-wide tree, default; 1 = 4-wide; 0 = binary), "stack_lds" (kernel instance). */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */

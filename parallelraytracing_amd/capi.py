@@ -66,7 +66,8 @@ class PrtStats(C.Structure):
 class PrtBvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("max_depth", C.c_uint32),
                 ("max_leaf_size", C.c_uint32), ("sah_cost", C.c_float), ("pad_abs", C.c_float),
-                ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("n_nodes4", C.c_uint32), ("max_stack4", C.c_uint32)]
+                ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("n_nodes4", C.c_uint32), ("max_stack4", C.c_uint32),
+                ("n_nodes8", C.c_uint32), ("depth8", C.c_uint32)]
 
 
 # numpy dtype mirror of PrtHit (40 bytes)
@@ -108,6 +109,7 @@ SIGNATURES = {
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_bvh_read4": (C.c_int, [_vp, _fp]),
+    "prt_bvh_read8": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "prt_set_variant": (C.c_int, [_vp, C.c_int]),
     "prt_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "prt_mesh_load_ply": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_size_t]),

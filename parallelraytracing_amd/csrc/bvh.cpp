@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <thread>
 
@@ -191,6 +192,8 @@ bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int 
     out->nodes.clear();
     out->nodes4.clear();
     out->max_stack4 = 0;
+    out->nodes8.clear();
+    out->depth8 = 0;
     out->order.clear();
     out->max_depth = 0;
     out->max_leaf = 0;
@@ -277,9 +280,245 @@ bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int 
         uint32_t build, dev;
     };
     auto is_leaf = [&](uint32_t ni) { return b.nodes[ni].left < 0; };
+    if (n_tris >= (1u << 26)) return false;  // 26-bit triangle slots (traversal work items carry 6 lane bits)
+
+    // ---- BVH8Q: collapse to 8 children, place them in octant-ordered slots, quantize (layout: bvh.h).  This also
+    // defines the triangle slot order of ALL trees: the leaf children of one wide node become contiguous. ----
+    std::vector<uint32_t> new_first(b.nodes.size(), 0);
+    std::vector<uint32_t> order_new(n_tris);
+    bool have8 = true;
+    {
+        std::vector<uint32_t> st{0};
+        while (!st.empty()) {
+            const uint32_t ni = st.back();
+            st.pop_back();
+            if (is_leaf(ni)) {
+                if (b.nodes[ni].count > 3) have8 = false;
+                continue;
+            }
+            st.push_back((uint32_t)b.nodes[ni].right);
+            st.push_back((uint32_t)b.nodes[ni].left);
+        }
+    }
+    if (have8) {
+        struct Item8 {
+            uint32_t build, dev, level;
+        };
+        // Which binary nodes become 8-wide nodes: the SAH-optimal collapse for this binary topology by dynamic
+        // programming (after Ylitie et al. 2017, section 3): cost[n][i] = least total area of wide nodes needed to
+        // represent the subtree of n with at most i+1 child slots of its wide parent.  The leaves are fixed, so the
+        // triangle term is a constant and only wide-node visits (probability ~ area) are minimised.  A greedy
+        // "expand the largest child" collapse leaves ~45 % of the nodes with two children; this one does not.
+        const uint32_t n_build = b.next_node.load();
+        std::vector<float> cost(8 * (size_t)n_build, 0.0f);   // [n][i], i = 0..6 <-> 1..7 slots; [n][7]: as a wide node's 8 slots
+        std::vector<uint8_t> pick(8 * (size_t)n_build, 0);    // split k (slots given to the left child); 0 = "use i-1 slots"
+        for (uint32_t ni = n_build; ni-- > 0;) {  // children have larger indices than their parent
+            if (is_leaf(ni)) continue;                          // leaves cost nothing extra in any number of slots
+            const float* cl = &cost[8 * (size_t)b.nodes[ni].left];
+            const float* cr = &cost[8 * (size_t)b.nodes[ni].right];
+            float* cn = &cost[8 * (size_t)ni];
+            uint8_t* pn = &pick[8 * (size_t)ni];
+            float dist[9];
+            uint8_t dk[9];
+            for (int j = 2; j <= 8; ++j) {  // distribute j slots over the two children
+                float bestc = FLT_MAX;
+                int bk = 1;
+                for (int k = 1; k < j; ++k) {
+                    const float c = cl[std::min(k, 7) - 1] + cr[std::min(j - k, 7) - 1];
+                    if (c < bestc) {
+                        bestc = c;
+                        bk = k;
+                    }
+                }
+                dist[j] = bestc;
+                dk[j] = (uint8_t)bk;
+            }
+            cn[0] = dist[8] + b.nodes[ni].box.half_area();  // one slot: n is a wide node of its own
+            pn[0] = 0;
+            pn[7] = dk[8];
+            cn[7] = dist[8];
+            for (int i = 2; i <= 7; ++i) {
+                if (dist[i] < cn[i - 2]) {
+                    cn[i - 1] = dist[i];
+                    pn[i - 1] = dk[i];
+                } else {
+                    cn[i - 1] = cn[i - 2];
+                    pn[i - 1] = 0;
+                }
+            }
+        }
+        // children of the wide node rooted at binary node ni
+        auto collapse8 = [&](uint32_t ni, uint32_t* kids) -> int {
+            int n = 0;
+            if (is_leaf(ni)) {
+                kids[n++] = ni;
+                return n;
+            }
+            struct Want {
+                uint32_t node;
+                int slots;
+            };
+            Want stk[32];
+            int top = 0;
+            const int k8 = pick[8 * (size_t)ni + 7];
+            stk[top++] = {(uint32_t)b.nodes[ni].right, 8 - k8};
+            stk[top++] = {(uint32_t)b.nodes[ni].left, k8};
+            while (top > 0) {
+                Want wn = stk[--top];
+                if (is_leaf(wn.node)) {
+                    kids[n++] = wn.node;
+                    continue;
+                }
+                int i = std::min(wn.slots, 7);
+                while (i > 1 && pick[8 * (size_t)wn.node + (i - 1)] == 0) --i;  // "use fewer slots"
+                if (i == 1) {
+                    kids[n++] = wn.node;  // stays an internal child (a wide node of its own)
+                    continue;
+                }
+                const int k = pick[8 * (size_t)wn.node + (i - 1)];
+                stk[top++] = {(uint32_t)b.nodes[wn.node].right, i - k};
+                stk[top++] = {(uint32_t)b.nodes[wn.node].left, k};
+            }
+            return n;
+        };
+        std::deque<Item8> queue;  // breadth first: the top of the tree is contiguous in memory
+        out->nodes8.assign(20, 0u);
+        queue.push_back({0, 0, 1});
+        uint32_t tri_cursor = 0;
+        while (!queue.empty() && have8) {
+            const Item8 it = queue.front();
+            queue.pop_front();
+            out->depth8 = std::max(out->depth8, it.level);
+            uint32_t kids[8];
+            const int n = collapse8(it.build, kids);
+            const Box& nb = b.nodes[it.build].box;
+            // slot assignment: slot s is visited FIRST by rays whose direction is negative exactly on the axes
+            // whose bit is set in s, so it should hold the child lying farthest towards +axis on those axes and
+            // towards -axis on the others; greedy on cost = dot(child centre - node centre, that diagonal)
+            int slot_of[8], child_in[8];
+            for (int k = 0; k < 8; ++k) slot_of[k] = child_in[k] = -1;
+            float cost[8][8];
+            for (int c = 0; c < n; ++c) {
+                const Box& cb = b.nodes[kids[c]].box;
+                float d[3];
+                for (int a = 0; a < 3; ++a) d[a] = (0.5f * cb.mn[a] + 0.5f * cb.mx[a]) - (0.5f * nb.mn[a] + 0.5f * nb.mx[a]);
+                for (int sl = 0; sl < 8; ++sl)
+                    cost[c][sl] = (((sl >> 0) & 1) ? d[0] : -d[0]) + (((sl >> 1) & 1) ? d[1] : -d[1]) + (((sl >> 2) & 1) ? d[2] : -d[2]);
+            }
+            for (int round = 0; round < n; ++round) {
+                int bc = -1, bs = -1;
+                float best = -FLT_MAX;
+                for (int c = 0; c < n; ++c) {
+                    if (slot_of[c] >= 0) continue;
+                    for (int sl = 0; sl < 8; ++sl)
+                        if (child_in[sl] < 0 && (bc < 0 || cost[c][sl] > best)) {
+                            best = cost[c][sl];
+                            bc = c;
+                            bs = sl;
+                        }
+                }
+                slot_of[bc] = bs;
+                child_in[bs] = bc;
+            }
+            // quantization grid per axis: origin = the node's own minimum, cell = 2^(eb - 127), 8 bits per plane
+            uint32_t eb[3];
+            double cell[3];
+            for (int a = 0; a < 3; ++a) {
+                const double p = nb.mn[a], ext = (double)nb.mx[a] - p;
+                const double big = std::max(std::fabs((double)nb.mn[a]), std::fabs((double)nb.mx[a]));
+                int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+                // keep p + q * cell exactly representable in a double (the containment checks below rely on it)
+                if (big > 0.0) e = std::max(e, (int)std::floor(std::log2(big)) - 30);
+                e = std::max(e, -126);
+                while (std::ceil(ext / std::ldexp(1.0, e)) > 255.0) ++e;
+                if (e > 126) have8 = false;
+                eb[a] = (uint32_t)(e + 127);
+                cell[a] = std::ldexp(1.0, e);
+            }
+            if (!have8) break;
+            uint32_t* w = &out->nodes8[20 * (size_t)it.dev];
+            uint32_t imask = 0, meta[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qlo[3][8], qhi[3][8];
+            const uint32_t child_base = (uint32_t)(out->nodes8.size() / 20);
+            const uint32_t tri_base = tri_cursor;
+            uint32_t n_inner = 0;
+            for (int sl = 0; sl < 8; ++sl) {
+                for (int a = 0; a < 3; ++a) {  // empty slot: inverted box, never referenced (meta = 0)
+                    qlo[a][sl] = 255;
+                    qhi[a][sl] = 0;
+                }
+                const int c = child_in[sl];
+                if (c < 0) continue;
+                const uint32_t kid = kids[c];
+                const Box& cb = b.nodes[kid].box;
+                for (int a = 0; a < 3; ++a) {
+                    const double p = nb.mn[a];
+                    double lo = std::floor(((double)cb.mn[a] - p) / cell[a]);
+                    while (lo > 0.0 && p + lo * cell[a] > (double)cb.mn[a]) lo -= 1.0;
+                    if (lo < 0.0) lo = 0.0;
+                    double hi = std::ceil(((double)cb.mx[a] - p) / cell[a]);
+                    while (p + hi * cell[a] < (double)cb.mx[a]) hi += 1.0;
+                    if (hi > 255.0 || lo > hi) have8 = false;
+                    qlo[a][sl] = (uint32_t)lo;
+                    qhi[a][sl] = (uint32_t)hi;
+                }
+                if (is_leaf(kid)) {
+                    const BuildNode& lf = b.nodes[kid];
+                    const uint32_t off = tri_cursor - tri_base;
+                    meta[sl] = (((1u << lf.count) - 1u) << 5) | off;  // unary count {1, 3, 7}; off <= 21
+                    new_first[kid] = tri_cursor;
+                    for (uint32_t k = 0; k < lf.count; ++k) order_new[tri_cursor + k] = b.order[lf.first + k];
+                    tri_cursor += lf.count;
+                } else {
+                    imask |= 1u << sl;
+                    meta[sl] = (1u << 5) | (24u + (uint32_t)sl);
+                    ++n_inner;
+                }
+            }
+            if (!have8) break;
+            // the internal children get consecutive node indices in slot order
+            out->nodes8.resize(out->nodes8.size() + 20 * (size_t)n_inner, 0u);
+            w = &out->nodes8[20 * (size_t)it.dev];
+            uint32_t rank = 0;
+            for (int sl = 0; sl < 8; ++sl)
+                if (imask & (1u << sl)) queue.push_back({kids[child_in[sl]], child_base + rank++, it.level + 1});
+            const float px = nb.mn[0], py = nb.mn[1], pz = nb.mn[2];
+            memcpy(&w[0], &px, 4);
+            memcpy(&w[1], &py, 4);
+            memcpy(&w[2], &pz, 4);
+            w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
+            w[4] = child_base;
+            w[5] = tri_base;
+            auto pack4 = [](const uint32_t* v) { return v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24); };
+            w[6] = pack4(meta);
+            w[7] = pack4(meta + 4);
+            w[8] = pack4(qlo[0]);  w[9] = pack4(qlo[0] + 4);
+            w[10] = pack4(qlo[1]); w[11] = pack4(qlo[1] + 4);
+            w[12] = pack4(qlo[2]); w[13] = pack4(qlo[2] + 4);
+            w[14] = pack4(qhi[0]); w[15] = pack4(qhi[0] + 4);
+            w[16] = pack4(qhi[1]); w[17] = pack4(qhi[1] + 4);
+            w[18] = pack4(qhi[2]); w[19] = pack4(qhi[2] + 4);
+        }
+        if (have8 && tri_cursor != n_tris) have8 = false;
+    }
+    if (!have8) {  // keep the builder's own order
+        out->nodes8.clear();
+        out->depth8 = 0;
+        std::vector<uint32_t> st{0};
+        while (!st.empty()) {
+            const uint32_t ni = st.back();
+            st.pop_back();
+            if (is_leaf(ni)) {
+                new_first[ni] = b.nodes[ni].first;
+                continue;
+            }
+            st.push_back((uint32_t)b.nodes[ni].right);
+            st.push_back((uint32_t)b.nodes[ni].left);
+        }
+        order_new = b.order;
+    }
     auto leaf_ref = [&](uint32_t ni) -> int32_t {
         const BuildNode& nd = b.nodes[ni];
-        return (int32_t) ~((nd.first << 4) | nd.count);
+        return (int32_t) ~((new_first[ni] << 4) | nd.count);
     };
     uint32_t n_internal = 0;
     {
@@ -293,7 +532,6 @@ bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int 
             st.push_back((uint32_t)b.nodes[ni].left);
         }
     }
-    if (n_tris >= (1u << 27)) return false;
     double sah = 0.0;
     const float root_area = std::max(root.box.half_area(), 1e-30f);
     if (is_leaf(0)) {
@@ -443,6 +681,6 @@ bool bvh_build(const float* verts, uint32_t n_tris, uint32_t max_leaf_size, int 
         }
         out->max_stack4 = need[0];
     }
-    out->order = std::move(b.order);
+    out->order = std::move(order_new);
     return out->max_depth <= max_allowed_depth;
 }

@@ -23,7 +23,7 @@
 namespace {
 
 constexpr float kPadCoeff = 1.0f / 262144.0f;  // 2^-18, see traverse() in prt_kernels.hip
-constexpr uint32_t kMaxLeaf = 4;
+constexpr uint32_t kMaxLeaf = 3;  // the compressed 8-wide node encodes at most 3 triangles per leaf (bvh.h)
 constexpr uint32_t kMaxStack = 63;  // LDS stack entries per lane: 31 (5 blocks/CU) or 63 (2 blocks/CU)
 
 struct EventPair {
@@ -54,6 +54,7 @@ struct PrtContext {
     void* d_mat_type = nullptr;
     void* d_nodes = nullptr;
     void* d_nodes4 = nullptr;
+    void* d_nodes8 = nullptr;
     void* d_tris = nullptr;
     void* d_nrms = nullptr;
 
@@ -87,7 +88,9 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
-    PrtTravTuning tune{1024u, 256u, 32u, 8u, 0u, 1u, 0u};  // grid 256 CUs x 4 blocks; stack_lds 0 = default instance  // XCD affinity measured 7 % slower on C3 (uneven eighths)  // grid 256 CUs x 5 blocks, 256-ray chunks (measured best)
+    // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
+    // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -203,6 +206,7 @@ void free_scene(PrtContext* c) {
     free_dev(c->d_mat_type);
     free_dev(c->d_nodes);
     free_dev(c->d_nodes4);
+    free_dev(c->d_nodes8);
     free_dev(c->d_tris);
     free_dev(c->d_nrms);
     c->has_scene = false;
@@ -405,7 +409,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         if (me.material_id >= s->n_materials) return fail(c, PRT_ERR_INVALID, "mesh %u: material out of range", m);
         n_tris += me.n_triangles;
     }
-    if (n_tris >= (1ull << 27)) return fail(c, PRT_ERR_INVALID, "too many triangles");
+    if (n_tris >= (1ull << 26)) return fail(c, PRT_ERR_INVALID, "too many triangles (limit 2^26 - 1)");
     std::vector<float> verts(9 * (size_t)n_tris);
     std::vector<float> norms(9 * (size_t)n_tris);
     std::vector<uint32_t> tri_mat((size_t)n_tris);
@@ -458,6 +462,8 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.node_bytes = (uint64_t)c->bvh.nodes4.size() * 4;
     bi.n_nodes4 = (uint32_t)(c->bvh.nodes4.size() / 32);
     bi.max_stack4 = c->bvh.max_stack4;
+    bi.n_nodes8 = (uint32_t)(c->bvh.nodes8.size() / 20);
+    bi.depth8 = c->bvh.depth8;
     bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
 
     DevScene& d = c->dsc;
@@ -504,6 +510,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
     HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
     HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
+    if (!c->bvh.nodes8.empty()) HIPCHECK(c, upload(&c->d_nodes8, c->bvh.nodes8.data(), c->bvh.nodes8.size() * 4));
     HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
     HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
     d.prims = (const DevPrim*)c->d_prims;
@@ -511,6 +518,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.mat_type = (const uint32_t*)c->d_mat_type;
     d.nodes = (const float4*)c->d_nodes;
     d.nodes4 = (const float4*)c->d_nodes4;
+    d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
     d.tris = (const float4*)c->d_tris;
     d.tri_normals = (const float4*)c->d_nrms;
     return ensure_counters(c);
@@ -890,6 +898,13 @@ int prt_bvh_read4(PrtContext* c, float* nodes4) {
     return PRT_OK;
 }
 
+int prt_bvh_read8(PrtContext* c, uint32_t* nodes8) {
+    if (!c) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (nodes8) memcpy(nodes8, c->bvh.nodes8.data(), c->bvh.nodes8.size() * 4);
+    return PRT_OK;
+}
+
 int prt_bvh_read(PrtContext* c, float* nodes, float* tris) {
     if (!c) return PRT_ERR_INVALID;
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
@@ -905,8 +920,9 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "grid_blocks" && value > 0 && value <= 8192) c->tune.grid_blocks = (uint32_t)value;
     else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
-    else if (n == "wide" && (value == 0 || value == 1)) c->tune.wide = (uint32_t)value;
-    else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "tri_min" && value >= 1 && value <= 1024) c->tune.tri_min = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
     else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;
     else return fail(c, PRT_ERR_INVALID, "unknown parameter or bad value: %s = %d", name, value);

@@ -30,6 +30,7 @@ struct DevScene {
     const uint32_t* mat_type;
     const float4* nodes;        // 4 x float4 per BVH2 node (see bvh.h)
     const float4* nodes4;       // 8 x float4 per BVH4 node (see bvh.h)
+    const uint4* nodes8;        // 5 x uint4 per compressed 8-wide node (see bvh.h); null if the tree has none
     const float4* tris;         // 3 x float4 per triangle, leaf order: {P0, prim}, {P1, material}, {P2, 0}
     const float4* tri_normals;  // 3 x float4 per triangle, leaf order
     uint32_t n_prims;
@@ -55,8 +56,9 @@ struct PrtTravTuning {
     uint32_t refill_min;   // idle lanes of a wave that trigger a refill
     uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf
     uint32_t xcd_affinity; // 1: each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
-    uint32_t wide;         // 1: walk the 4-wide tree (default), 0: the binary tree
-    uint32_t stack_lds;    // per-lane stack entries kept in LDS: 31 (5 blocks/CU) or 24 (6 blocks/CU, trees of depth <= 24)
+    uint32_t wide;         // 2: walk the compressed 8-wide tree (default), 1: the 4-wide tree, 0: the binary tree
+    uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles
+    uint32_t stack_lds;    // selects the kernel instance (stack entries in LDS / waves per SIMD), see prt_launch_traverse
 };
 
 struct PrtRayBuf {

@@ -1109,6 +1109,322 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Default traversal: persistent waves over the COMPRESSED 8-WIDE tree (BVH8Q, layout in bvh.h).
+//
+// Why: the 4-wide kernel above is bound by dependent node fetches that miss the 4 MB per-XCD L2 (C3: 37 MB of
+// 128-B nodes, L2 hit 46 %, 3.4 TB/s leaving the L2s, waves parked on s_waitcnt 64 % of their cycles).  An 8-wide
+// node with 8-bit quantized child boxes is 80 B for 8 children: the whole C3 node array is ~5 MB, a ray needs
+// ~0.6x as many dependent fetches, and a step needs no sorting network: the children sit in octant-ordered slots, a
+// step produces a hit MASK, and the stack holds one (child base, pending hit mask) "node group" per level
+// (after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", 2017;
+// this formulation is for wave64 with the stack in LDS and cooperative triangle tests).
+//
+// Per lane: G = (child_base, pending internal hits in bits 24..31 by visiting priority | imask in bits 0..7) and
+// up to two pending TRIANGLE groups (tri_base, 24-bit mask): the first one found is postponed while the lane keeps
+// walking, a second one stops the lane until the wave's next triangle phase.  There all pending (ray, triangle)
+// pairs of the wave are written to an LDS work queue and tested one pair per lane per round; results are merged per
+// owner with a 64-bit LDS atomicMin on (d2 bits << 32 | primitive index) = the reference's rule (primitive.cpp:42-48).
+// Culling stays conservative: the quantized boxes contain the exact ones (bvh.cpp verifies it in exact arithmetic),
+// near planes move out by -pad and far planes by +pad exactly as in the 4-wide kernel, so results are bit-identical.
+// A ray that would need more than STACK_L stacked groups goes to the overflow list (re-traversed by the 4-wide
+// spill-capable instance); the host sizes STACK_L from the tree's depth, so that never happens in practice.
+// ---------------------------------------------------------------------------------------------------------
+#define T8_QCAP 256u  // work items of one wave between two triangle phases
+
+template <int STACK_L, int WAVES, bool STATS>
+__global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
+                                                                    const float4* __restrict__ rd,
+                                                                    uint32_t* __restrict__ hit,
+                                                                    const float* __restrict__ hd2,
+                                                                    const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ work,
+                                                                    uint32_t* __restrict__ ovf, PrtTravTuning tune,
+                                                                    unsigned long long* __restrict__ stats) {
+    __shared__ uint2 s_stack[(STACK_L + 1) * 256];  // [entry][thread]; one row of slack above the top
+    __shared__ unsigned long long s_key[256];       // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
+    __shared__ uint32_t s_slot[256];                // per lane: leaf-order slot of that best
+    __shared__ uint32_t s_queue[4 * T8_QCAP];       // per wave: (owner lane << 26) | triangle slot
+    __shared__ uint32_t s_qn[8];                    // per wave: [w] items appended so far, [4 + w] first position that did not fit
+    __shared__ uint32_t s_iters[8];                 // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
+    const uint32_t count = *count_ptr;
+    const uint32_t chunk = tune.chunk;
+    const uint32_t n_chunks = (count + chunk - 1u) / chunk;
+    const uint32_t my_xcd = xcc_id();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t wv = tid >> 6;
+    const uint32_t wbase = tid & ~63u;
+    if (tid < 8) {
+        s_iters[tid] = 0;
+        s_qn[tid] = tid < 4 ? 0u : T8_QCAP;
+    }
+    __syncthreads();
+    uint32_t* const queue = &s_queue[wv * T8_QCAP];
+    uint32_t k = 0xFFFFFFFFu;
+    f3 o = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
+    float ix = 1.f, iy = 1.f, iz = 1.f, anx = 0.f, any = 0.f, anz = 0.f, afx = 0.f, afy = 0.f, afz = 0.f, pad = 0.f, tlimit = 0.f;
+    uint32_t octinv = 7u, octinv4 = 0x07070707u;
+    uint32_t gx = 0u, gy = 0u;    // current node group
+    uint32_t tBb = 0u, tBm = 0u;  // a triangle group that did not fit the queue (the lane waits for the next phase)
+    bool pending = false;         // this lane has items in the wave's queue
+    int sp = 0;
+    bool overflow = false;
+    Closest best;
+    best.d2 = 3.402823466e+38f;
+    best.id = HIT_MISS;
+    best.prim = 0xFFFFFFFFu;
+    uint32_t n_nodes = 0, n_tris = 0, max_sp = 0;
+    uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
+    bool exhausted = false;         // wave-uniform
+    uint32_t q_lanes = 0;           // wave-uniform: lane-steps that queued triangles since the last phase (<= items)
+    // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
+    // idle; every outer iteration makes progress (a node step, a triangle phase or a refill); the iteration cap is
+    // a watchdog that turns a would-be hang into an error flag the host reports.
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > (1u << 22)) {
+            if (lane == 0) atomicOr(work + 256, 1u);
+            break;
+        }
+        // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
+        if (k != 0xFFFFFFFFu && !pending && tBm == 0u) {
+            if (overflow) {
+                const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable 4-wide instance
+                if (j < PRT_OVF_CAP)
+                    ovf[1u + j] = k;
+                else
+                    atomicOr(work + 256, 2u);
+                overflow = false;
+                k = 0xFFFFFFFFu;
+            } else if (!(gy > 0x00FFFFFFu) && sp == 0) {
+                hit[k] = best.id;
+                k = 0xFFFFFFFFu;
+            }
+        }
+        const bool idle = k == 0xFFFFFFFFu;
+        const unsigned long long idle_mask = __ballot(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (!exhausted && n_idle >= tune.refill_min) {
+            if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
+                uint32_t c = 0xFFFFFFFFu;
+                if (lane == 0) c = grab_chunk(work, n_chunks, my_xcd, tune.xcd_affinity != 0u);
+                c = (uint32_t)__shfl((int)c, 0, 64);
+                if (c == 0xFFFFFFFFu) {
+                    exhausted = true;
+                } else {
+                    cur = c * chunk;
+                    cur_end = (cur + chunk < count) ? cur + chunk : count;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t qi = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && qi < cur_end) {
+                    const uint32_t hid = hit[qi];
+                    if (hid != HIT_DEAD) {
+                        const float4 O = ro[qi];
+                        const float4 D = rd[qi];
+                        o = mk3(O.x, O.y, O.z);
+                        ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
+                        pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        // near planes move out by -pad, far planes by +pad (the near plane is the box's max plane
+                        // on an axis the ray travels along negatively):  t = plane * inv - (o +- pad) * inv
+                        const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+                        anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
+                        any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
+                        anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
+                        octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+                        octinv4 = octinv * 0x01010101u;
+                        best.id = hid;
+                        best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
+                        best.d2 = hd2[qi];
+                        tlimit = limit_from_d2(best.d2, pad);
+                        k = qi;
+                        gx = 0u;  // the root "group": node 0, one pending hit that decodes to slot 0
+                        gy = 1u << (24u + octinv);
+                        sp = 0;
+                    }
+                }
+                cur = (cur + n_idle < cur_end) ? cur + n_idle : cur_end;
+            }
+        }
+        if (__ballot(k != 0xFFFFFFFFu) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- phase 1: node steps.  Triangles found go straight to the wave's queue and the lane keeps walking;
+        // leave when at most exit_max lanes can still walk or enough work for a triangle phase has piled up ----
+        bool walk = (k != 0xFFFFFFFFu) && tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0);
+        while (walk) {
+            // current group: G while it has pending internal hits, else the top of the stack (read unconditionally)
+            const int spr = sp > 0 ? sp - 1 : 0;
+            const uint2 top = s_stack[spr * 256 + tid];
+            const bool has = gy > 0x00FFFFFFu;
+            const uint32_t cx = has ? gx : top.x;
+            uint32_t cy = has ? gy : top.y;
+            sp = has ? sp : spr;
+            const uint32_t bit = 31u - (uint32_t)__builtin_clz(cy);  // highest pending hit: bits 24..31
+            cy &= ~(1u << bit);
+            s_stack[sp * 256 + tid] = make_uint2(cx, cy);  // the remaining siblings (kept only if there are any)
+            sp += (cy > 0x00FFFFFFu) ? 1 : 0;
+            const uint32_t slot = (bit - 24u) ^ octinv;
+            const uint32_t idx = cx + (uint32_t)__popc(cy & ((1u << slot) - 1u));  // bits 0..7 of cy: imask
+            const uint4* nb = sc.nodes8 + 5 * (size_t)idx;
+            const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
+            if (STATS) {
+                ++n_nodes;
+                if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[wv];
+                if ((uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+            }
+            const uint32_t eim = w0.w;
+            const float Ax = __uint_as_float((eim & 0xFFu) << 23) * ix;
+            const float Ay = __uint_as_float(((eim >> 8) & 0xFFu) << 23) * iy;
+            const float Az = __uint_as_float(((eim >> 16) & 0xFFu) << 23) * iz;
+            const float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);
+            const float Bnx = __builtin_fmaf(px, ix, -anx), Bny = __builtin_fmaf(py, iy, -any), Bnz = __builtin_fmaf(pz, iz, -anz);
+            const float Bfx = __builtin_fmaf(px, ix, -afx), Bfy = __builtin_fmaf(py, iy, -afy), Bfz = __builtin_fmaf(pz, iz, -afz);
+            const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+            // quantized planes, children 0..3 (a) and 4..7 (b): w2 = {lox a, lox b, loy a, loy b},
+            // w3 = {loz a, loz b, hix a, hix b}, w4 = {hiy a, hiy b, hiz a, hiz b}
+            const uint32_t nxa = nx ? w3.z : w2.x, nxb = nx ? w3.w : w2.y, fxa = nx ? w2.x : w3.z, fxb = nx ? w2.y : w3.w;
+            const uint32_t nya = ny ? w4.x : w2.z, nyb = ny ? w4.y : w2.w, fya = ny ? w2.z : w4.x, fyb = ny ? w2.w : w4.y;
+            const uint32_t nza = nz ? w4.z : w3.x, nzb = nz ? w4.w : w3.y, fza = nz ? w3.x : w4.z, fzb = nz ? w3.y : w4.w;
+            uint32_t hitmask = 0u;
+            // The per-ray pad (2^-18 (|o|_1 + extent) in position space) exceeds the rounding of these plane distances
+            // (a few 2^-24 of the same magnitude) by a factor > 10, so no relative slack is needed on top of it.
+#define T8_CHILD(J, NX, FX, NY, FY, NZ, FZ)                                                                          \
+    {                                                                                                                \
+        /* scalar FMAs: v_pk_fma_f32 measured 3.5 % slower here (12.95 -> 12.68 Grays/s on C3) */                   \
+        const float tnx = __builtin_fmaf((float)(((NX) >> (8 * J)) & 0xFFu), Ax, Bnx);                               \
+        const float tny = __builtin_fmaf((float)(((NY) >> (8 * J)) & 0xFFu), Ay, Bny);                               \
+        const float tnz = __builtin_fmaf((float)(((NZ) >> (8 * J)) & 0xFFu), Az, Bnz);                               \
+        const float tfx = __builtin_fmaf((float)(((FX) >> (8 * J)) & 0xFFu), Ax, Bfx);                               \
+        const float tfy = __builtin_fmaf((float)(((FY) >> (8 * J)) & 0xFFu), Ay, Bfy);                               \
+        const float tfz = __builtin_fmaf((float)(((FZ) >> (8 * J)) & 0xFFu), Az, Bfz);                               \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));                     \
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlimit));                   \
+        const uint32_t cb = ((bits4 >> (8 * J)) & 0xFFu) << ((idx4 >> (8 * J)) & 0xFFu);                             \
+        hitmask |= (tn <= tf) ? cb : 0u;                                                                             \
+    }
+#define T8_HALF(META4, NX, FX, NY, FY, NZ, FZ)                                                                       \
+    {                                                                                                                \
+        const uint32_t meta4 = (META4);                                                                              \
+        const uint32_t in4 = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4; /* 1 in the bytes of internal children */  \
+        const uint32_t idx4 = (meta4 ^ (octinv4 & ((in4 << 3) - in4))) & 0x1F1F1F1Fu;                                \
+        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;                                                           \
+        T8_CHILD(0, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(1, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(2, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(3, NX, FX, NY, FY, NZ, FZ)                                                                          \
+    }
+            T8_HALF(w1.z, nxa, fxa, nya, fya, nza, fza)
+            T8_HALF(w1.w, nxb, fxb, nyb, fyb, nzb, fzb)
+#undef T8_HALF
+#undef T8_CHILD
+            gx = w1.x;
+            gy = (hitmask & 0xFF000000u) | (eim >> 24);
+            const uint32_t tm = hitmask & 0x00FFFFFFu;
+            if (sp > STACK_L) {  // give the ray up; it is re-traversed through the overflow list
+                overflow = true;
+                gy = 0u;
+                sp = 0;
+            } else if (tm != 0u) {
+                const uint32_t cnt = (uint32_t)__popc(tm);
+                const uint32_t pos = atomicAdd(&s_qn[wv], cnt);
+                if (pos + cnt <= T8_QCAP) {
+                    uint32_t qp = pos;
+                    for (uint32_t m = tm; m; m &= m - 1u) queue[qp++] = (lane << 26) | (w1.y + (uint32_t)__builtin_ctz(m));
+                    pending = true;
+                } else {  // queue full (everything appended later fails as well): wait for the next phase
+                    atomicMin(&s_qn[4 + wv], pos);
+                    tBb = w1.y;
+                    tBm = tm;
+                }
+            }
+            q_lanes += (uint32_t)__popcll(__ballot(tm != 0u));
+            walk = tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0);
+            if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
+        }
+        // ---- phase 2: the queued (ray, triangle) pairs, one pair per lane per round ----
+        {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const uint32_t qn = ((volatile uint32_t*)s_qn)[wv], qv = ((volatile uint32_t*)s_qn)[4 + wv];
+            const uint32_t T0 = qn < qv ? qn : qv;  // valid prefix of the queue
+            const uint32_t cntB = (uint32_t)__popc(tBm);
+            if (T0 != 0u || __ballot(cntB != 0u) != 0ull) {  // wave-uniform
+                // groups that did not fit are appended now, in lane order, as far as they fit
+                const uint32_t incl = wave_scan_add(cntB);
+                const bool fits = T0 + incl <= T8_QCAP;  // true for a prefix of the lanes
+                const uint32_t n_fit = (uint32_t)__popcll(__ballot(fits));
+                const uint32_t T = n_fit ? T0 + (uint32_t)__shfl((int)incl, (int)(n_fit - 1u), 64) : T0;
+                if (fits && cntB) {
+                    uint32_t qp = T0 + incl - cntB;
+                    for (uint32_t m = tBm; m; m &= m - 1u) queue[qp++] = (lane << 26) | (tBb + (uint32_t)__builtin_ctz(m));
+                    tBm = 0u;
+                }
+                // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
+                const unsigned long long key_best =
+                    ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
+                s_key[tid] = key_best;
+                if (lane == 0) {
+                    s_qn[wv] = 0u;
+                    s_qn[4 + wv] = T8_QCAP;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                for (uint32_t base = 0; base < T; base += 64u) {  // wave-uniform trip count
+                    const uint32_t kq = base + lane;
+                    const bool act = kq < T;
+                    const uint32_t item = ((volatile uint32_t*)queue)[act ? kq : 0u];
+                    const uint32_t owner = act ? (item >> 26) : lane;
+                    const uint32_t slot = item & 0x03FFFFFFu;
+                    const f3 qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
+                    const f3 qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                    bool cand = false;
+                    unsigned long long key = 0ull;
+                    if (act) {
+                        const float4 a = sc.tris[3 * (size_t)slot + 0];
+                        const float4 b = sc.tris[3 * (size_t)slot + 1];
+                        const float4 c = sc.tris[3 * (size_t)slot + 2];
+                        if (STATS) ++n_tris;
+                        f3 pos;
+                        float b1, b2;
+                        if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), qo, qd, pos, b1, b2)) {
+                            const float d2 = dist2(qo, pos);
+                            key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(a.w);
+                            // NaN / inf d2 have bit patterns above FLT_MAX's: they can never win, as in the reference
+                            cand = true;
+                            atomicMin(&s_key[wbase + owner], key);
+                        }
+                    }
+                    if (STATS && lane == 0) ++s_iters[4 + wv];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = slot;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                const unsigned long long won = ((volatile unsigned long long*)s_key)[tid];
+                if (won != key_best) {
+                    best.d2 = __uint_as_float((uint32_t)(won >> 32));
+                    best.prim = (uint32_t)won;
+                    best.id = sc.n_prims + ((volatile uint32_t*)s_slot)[tid];
+                    tlimit = limit_from_d2(best.d2, pad);
+                }
+                pending = false;  // everything that was queued has been tested
+                q_lanes = 0u;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        __syncthreads();
+        if (threadIdx.x < 4) atomicAdd(&stats[3], 64ull * s_iters[threadIdx.x]);
+        if (threadIdx.x < 4) atomicAdd(&stats[4], 64ull * s_iters[4 + threadIdx.x]);
+        atomicMax(&stats[5], (unsigned long long)max_sp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Shade + scatter + compaction (ShadeHitsKernel, renderer.cu:274-335; the miss branch of
 // IntersectClosestKernel, renderer.cu:263-271; path logic of TraceRayGPU, cuda_megakernel/renderer.cu:81-119).
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
@@ -1390,7 +1706,26 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((KERNEL<L, W, MODE, false>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,    \
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
-    if (tune.wide) {
+    if (tune.wide == 2u && sc.nodes8) {
+        // default: compressed 8-wide tree; a ray needs at most depth8 - 1 stacked node groups.  15 entries at
+        // 4 waves/SIMD or 11 entries at 5 waves/SIMD (tune.stack_lds == 5); deeper rays take the overflow list.
+#define PRT_LAUNCH_8(L, W)                                                                                         \
+    do {                                                                                                           \
+        if (stats)                                                                                                 \
+            hipLaunchKernelGGL((k_traverse8_persistent<L, W, true>), grid, block, 0, st, sc, in.o, in.d, in.hit,   \
+                               in.hd2, count_ptr, work, ovf, tune, stats);                                         \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_traverse8_persistent<L, W, false>), grid, block, 0, st, sc, in.o, in.d, in.hit,  \
+                               in.hd2, count_ptr, work, ovf, tune, stats);                                         \
+    } while (0)
+        if (tune.stack_lds == 5u)
+            PRT_LAUNCH_8(11, 5);
+        else
+            PRT_LAUNCH_8(15, 4);
+#undef PRT_LAUNCH_8
+        hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+        PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
+    } else if (tune.wide) {
         if (stack4 <= 22 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 22, 6, 0, grid, count_ptr, no_list);
         else if (stack4 <= 27) PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 0, grid, count_ptr, no_list);
         else if (tune.stack_lds == 39 && stack4 <= 35) PRT_LAUNCH_T(k_traverse4_persistent, 35, 4, 0, grid, count_ptr, no_list);

@@ -418,6 +418,13 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_bvh_read4(self._ctx, nodes4.ctypes.data_as(_fp)))
         return nodes4
 
+    def bvh_read8(self) -> np.ndarray:
+        """The compressed 8-wide tree: [n_nodes8, 20] uint32 (layout: csrc/bvh.h)."""
+        b = self.bvh_info()
+        nodes8 = np.zeros((b.n_nodes8, 20), np.uint32)
+        self._check(capi.lib().prt_bvh_read8(self._ctx, nodes8.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return nodes8
+
     def set_scene_host_only(self, scene: Scene):
         """For host-only contexts (device < 0): build the BVH without a GPU."""
         d = scene.desc()

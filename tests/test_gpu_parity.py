@@ -109,7 +109,7 @@ def test_closest_hit_refined_mesh_vs_oracle_bvh_bit_exact():
 
 
 def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
-    """The headline mesh (dragon refined to 870,000 triangles; deep 4-wide tree -> LDS + global-spill stack)."""
+    """The headline mesh (dragon refined to 870,000 triangles), every traversal kernel instance."""
     scene, cam, W, H, spp, depth = prt.scenes.config("C3")
     r, _, _ = make_renderer(scene, 64, 36, cam=prt.Camera(cam.position, width=64, height=36))
     info = r.bvh_info()
@@ -128,10 +128,20 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
         r.set_variant(v)
         assert util.hits_equal(r.closest_hit(o, d), want) == []
     r.set_variant(0)
-    for name, val in (("wide", 0), ("stack_lds", 1), ("stack_lds", 2), ("stack_lds", 3), ("stack_lds", 39), ("xcd_affinity", 1), ("chunk", 64)):
-        r.set_param(name, val)  # every tunable / kernel instance gives the same hits
-        assert util.hits_equal(r.closest_hit(o, d), want) == [], (name, val)
-        r.set_param("wide", 1)
+    assert info.n_nodes8 > 0 and info.depth8 <= 16
+    # every tunable / kernel instance gives the same hits: the compressed 8-wide tree (default, wide = 2) at both
+    # occupancies, the 4-wide tree's instances (wide = 1), the binary tree (wide = 0)
+    for wide, name, val in ((2, "stack_lds", 5), (2, "chunk", 64), (2, "xcd_affinity", 1), (2, "exit_max", 0), (2, "refill_min", 1),
+                            (1, "stack_lds", 0), (1, "stack_lds", 1), (1, "stack_lds", 2), (1, "stack_lds", 3),
+                            (1, "stack_lds", 39), (1, "xcd_affinity", 1), (1, "chunk", 64), (0, "stack_lds", 0)):
+        r.set_param("wide", wide)
+        r.set_param(name, val)
+        assert util.hits_equal(r.closest_hit(o, d), want) == [], (wide, name, val)
+        for k_, v_ in (("stack_lds", 0), ("chunk", 256), ("xcd_affinity", 0), ("exit_max", 8), ("refill_min", 32)):
+            r.set_param(k_, v_)
+    r.set_param("wide", 2)
+    st = r.measure_traversal()
+    assert st.max_stack_used < info.depth8 and st.bvh_node_visits > 0
 
 
 def test_scatter_bit_exact_all_materials():

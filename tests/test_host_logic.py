@@ -224,7 +224,7 @@ def test_bvh_structure(ply, target):
     info = r.bvh_info()
     nodes, tris = r.bvh_read()
     nt = mesh.n_triangles
-    assert info.n_triangles == nt and info.max_leaf_size <= 4 and info.max_depth <= 64
+    assert info.n_triangles == nt and info.max_leaf_size <= 3 and info.max_depth <= 64
     leaves, refs = _leaf_ranges(nodes)
     covered = np.zeros(nt, np.int32)
     for node, side, first, cnt in leaves:
@@ -286,7 +286,7 @@ def test_bvh4_structure(ply, target):
             if ref < 0:
                 u = (~ref) & 0xFFFFFFFF
                 first, cnt = u >> 4, u & 15
-                assert 1 <= cnt <= 4
+                assert 1 <= cnt <= 3
                 covered[first:first + cnt] += 1
                 P = tris[first:first + cnt].reshape(cnt, 3, 4)[:, :, :3].reshape(-1, 3)
                 assert (P >= lo).all() and (P <= hi).all()
@@ -353,6 +353,160 @@ def test_bvh_python_traversal_agrees_with_oracle_linear_scan():
                         u = (~c) & 0xFFFFFFFF
                         reached.update(prim_of_slot[(u >> 4):(u >> 4) + (u & 15)].tolist())
         assert int(want["prim"][k]) in reached
+
+
+# ---- compressed 8-wide tree (bvh.h "BVH8Q"): what the default traversal kernel walks ----------------------------------
+def _decode8(n8):
+    """Fields of the [n, 20] uint32 node array."""
+    p = n8[:, 0:3].copy().view(np.float32).astype(np.float64)
+    eb = np.stack([(n8[:, 3] >> (8 * a)) & 0xFF for a in range(3)], axis=1).astype(np.int64)
+    cell = np.ldexp(1.0, eb - 127)
+    imask = (n8[:, 3] >> 24).astype(np.int64)
+    meta = np.stack([(n8[:, 6 + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.int64)
+
+    def planes(w):  # 8 bytes from words w, w+1
+        return np.stack([(n8[:, w + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.float64)
+    qlo = np.stack([planes(8), planes(10), planes(12)], axis=2)   # [n, child, axis]
+    qhi = np.stack([planes(14), planes(16), planes(18)], axis=2)
+    lo = p[:, None, :] + qlo * cell[:, None, :]
+    hi = p[:, None, :] + qhi * cell[:, None, :]
+    return dict(p=p, imask=imask, meta=meta, lo=lo, hi=hi, child_base=n8[:, 4].astype(np.int64),
+                tri_base=n8[:, 5].astype(np.int64))
+
+
+@pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("dragon.ply", 60_000)])
+def test_bvh8_structure(ply, target):
+    mesh = prt.Mesh(prt.scenes.asset(ply))
+    if target:
+        mesh.refine(target)
+    sc = prt.scenes.mesh_scene(mesh)
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    info = r.bvh_info()
+    n8 = r.bvh_read8()
+    _, tris = r.bvh_read()
+    nt = mesh.n_triangles
+    assert info.n_nodes8 == len(n8) > 0 and info.max_leaf_size <= 3
+    D = _decode8(n8)
+    V = tris.reshape(nt, 3, 4)[:, :, :3].astype(np.float64)
+    covered = np.zeros(nt, np.int32)
+    seen = np.zeros(len(n8), np.int32)
+    exact_lo = np.full((len(n8), 3), np.inf)
+    exact_hi = np.full((len(n8), 3), -np.inf)
+    level = np.zeros(len(n8), np.int32)
+    level[0] = 1
+    fill = []
+    # children have larger indices than their parent (breadth-first layout): one reverse pass gives exact bounds
+    kids = [[] for _ in range(len(n8))]
+    for n in range(len(n8)):
+        rank, m = 0, 0
+        for i in range(8):
+            meta = int(D["meta"][n, i])
+            inner = (D["imask"][n] >> i) & 1
+            if meta == 0:
+                assert not inner
+                continue
+            m += 1
+            if inner:
+                assert meta == (1 << 5) | (24 + i)
+                c = int(D["child_base"][n]) + rank
+                rank += 1
+                assert n < c < len(n8)
+                seen[c] += 1
+                level[c] = level[n] + 1
+                kids[n].append((i, c))
+            else:
+                unary, off = meta >> 5, meta & 31
+                assert unary in (1, 3, 7) and off + bin(unary).count("1") <= 24
+                cnt = bin(unary).count("1")
+                first = int(D["tri_base"][n]) + off
+                covered[first:first + cnt] += 1
+                P = V[first:first + cnt].reshape(-1, 3)
+                assert (P >= D["lo"][n, i]).all() and (P <= D["hi"][n, i]).all()   # quantized box contains the leaf
+                exact_lo[n] = np.minimum(exact_lo[n], P.min(axis=0))
+                exact_hi[n] = np.maximum(exact_hi[n], P.max(axis=0))
+        fill.append(m)
+    assert (covered == 1).all() and (seen[1:] == 1).all() and seen[0] == 0
+    for n in range(len(n8) - 1, -1, -1):
+        for i, c in kids[n]:
+            # the quantized box of an internal child contains everything below it
+            assert (exact_lo[c] >= D["lo"][n, i]).all() and (exact_hi[c] <= D["hi"][n, i]).all()
+            exact_lo[n] = np.minimum(exact_lo[n], exact_lo[c])
+            exact_hi[n] = np.maximum(exact_hi[n], exact_hi[c])
+    assert np.array_equal(exact_lo[0], V.reshape(-1, 3).min(axis=0)) and np.array_equal(D["p"][0], exact_lo[0])
+    assert info.depth8 == level.max() and info.depth8 <= 16
+    print("bvh8 fill", np.mean(fill), len(n8), info.depth8, np.bincount(fill))
+    assert np.mean(fill) > 5.0 or len(n8) < 16   # the collapse fills the nodes
+    assert len(n8) * 80 < info.node_bytes / 2 or len(n8) < 16   # far smaller than the 4-wide tree
+
+
+def test_bvh8_python_traversal_agrees_with_oracle_linear_scan():
+    """numpy emulation of k_traverse8_persistent's node-group / hit-mask logic (same bit operations, boxes decoded in
+    float64 with a small slack): the triangles it reaches always include the oracle's linear-scan winner, and rays
+    of all eight direction octants are covered."""
+    mesh = prt.Mesh(prt.scenes.asset("bunny.ply"))
+    sc = prt.Scene(preset=None)
+    sc.AddMesh(mesh, sc.AddLambertian((1, 1, 1)))
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    n8 = r.bvh_read8()
+    _, tris = r.bvh_read()
+    D = _decode8(n8)
+    prim_of_slot = tris[:, 3].view(np.uint32)
+    rng = np.random.default_rng(5)
+    o, d = util.random_rays(rng, 160, center=(0, 0, 0), radius=6.0, spread=0.8)
+    o[:, 1] *= np.where(rng.random(len(o)) < 0.5, -1, 1).astype(np.float32)   # also rays travelling upwards
+    d = np.stack([prt.glm_normalize(v) for v in (-o + rng.uniform(-0.8, 0.8, size=o.shape).astype(np.float32))])
+    want = util.oracle_scene(sc).closest_hit(o, d, use_bvh=False, n_threads=8)
+    assert (want["prim"] >= 0).sum() > 60
+    octs = set()
+    max_sp = 0
+    for k in range(len(o)):
+        if want["prim"][k] < 0:
+            continue
+        dk = d[k].astype(np.float64)
+        inv = 1.0 / np.where(np.abs(dk) < 1e-20, 1e-20, dk)
+        neg = inv < 0
+        octinv = 7 - (int(neg[0]) | int(neg[1]) << 1 | int(neg[2]) << 2)
+        octs.add(octinv)
+        tlimit = np.sqrt(float(want["d2"][k])) * 1.001 + 1e-3
+        reached = []
+        gx, gy, stack = 0, 1 << (24 + octinv), []
+        order_ok = True
+        while True:
+            if not gy > 0x00FFFFFF:
+                if not stack:
+                    break
+                gx, gy = stack.pop()
+            bit = gy.bit_length() - 1
+            assert 24 <= bit <= 31
+            gy &= ~(1 << bit)
+            if gy > 0x00FFFFFF:
+                stack.append((gx, gy))
+                max_sp = max(max_sp, len(stack))
+            slot = (bit - 24) ^ octinv
+            idx = gx + bin(gy & ((1 << slot) - 1) & 0xFF).count("1")
+            lo, hi = D["lo"][idx] - 1e-4, D["hi"][idx] + 1e-4
+            near = np.where(neg, hi, lo)
+            far = np.where(neg, lo, hi)
+            tn = np.maximum(((near - o[k]) * inv).max(axis=1), 0.0)
+            tf = np.minimum(((far - o[k]) * inv).min(axis=1), tlimit)
+            hitmask = 0
+            for i in range(8):
+                meta = int(D["meta"][idx, i])
+                if meta == 0 or not tn[i] <= tf[i]:
+                    continue
+                inner = (meta & (meta << 1)) & 0x10
+                bidx = (meta ^ (octinv if inner else 0)) & 0x1F
+                hitmask |= (meta >> 5) << bidx
+            gx, gy = int(D["child_base"][idx]), (hitmask & 0xFF000000) | int(D["imask"][idx])
+            tm = hitmask & 0x00FFFFFF
+            while tm:
+                t = (tm & -tm).bit_length() - 1
+                tm &= tm - 1
+                reached.append(int(prim_of_slot[int(D["tri_base"][idx]) + t]))
+        assert int(want["prim"][k]) in reached and len(reached) == len(set(reached)) and order_ok
+    assert len(octs) == 8 and max_sp < r.bvh_info().depth8
 
 
 # ---- tile map / partition (dist.py restates the kernels' tile layout) ---------------------------------------------------
