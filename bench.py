@@ -107,6 +107,8 @@ def main():
     r.Init(film, scene, cam)
     r.set_variant(args.variant)
     r.set_param("wide", args.wide)
+    if os.environ.get("PRT_FUSE"):  # A/B: 0 = the producers store every ray (no fused analytic segment)
+        r.set_param("fuse", int(os.environ["PRT_FUSE"]))
     n_tris = scene.n_triangles
     bvh = r.bvh_info()
     spp_step = args.spp_per_step or spp_total  # a step = one complete frame of the config

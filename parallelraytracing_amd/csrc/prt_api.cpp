@@ -90,7 +90,7 @@ struct PrtContext {
     int variant = 0;
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -274,12 +274,16 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     if (rc) return rc;
     const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
     if ((rc = ensure_spill(c))) return rc;
+    // A/B option (off by default, measured 11 % slower on C3: the fused producers need 78 / 119 VGPRs instead of 64 /
+    // 72 and lose more to occupancy than they save in ray traffic): analytic-only segments shaded inside the
+    // producers, only when the scene has a BVH and few analytic primitives
+    const uint32_t fuse = (c->dsc.n_nodes && c->dsc.n_prims <= 16u) ? c->tune.fuse : 0u;
     EventPair ep{};
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
     if ((rc = begin_event(c, 0, &ep))) return rc;
     prt_launch_raygen(c->stream, c->dsc, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts,
-                      c->d_work);
+                      c->d_work, max_depth, fuse);
     if ((rc = end_event(c, &ep))) return rc;
     for (uint32_t d = 0; d < max_depth; ++d) {
         const PrtRayBuf& in = c->rb[d & 1];
@@ -296,16 +300,15 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             ++c->stats.intersect_launches;
         }
         if ((rc = begin_event(c, 2, &ep))) return rc;
-        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths);
+        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse);
         if ((rc = end_event(c, &ep))) return rc;
     }
-    if (accumulate) {
-        if ((rc = begin_event(c, 3, &ep))) return rc;
-        prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, c->d_counts, max_depth,
-                              c->d_ray_stats);
-        if ((rc = end_event(c, &ep))) return rc;
-        c->stats.samples += S_cur;
-    }
+    // film += the batch's samples (unless this is a measurement run) and per-depth ray counts from the paths' last
+    // segment indices
+    if ((rc = begin_event(c, 3, &ep))) return rc;
+    prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats);
+    if ((rc = end_event(c, &ep))) return rc;
+    if (accumulate) c->stats.samples += S_cur;
     HIPCHECK(c, hipGetLastError());
     return PRT_OK;
 }
@@ -855,11 +858,16 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     const bool timing = c->timing;
     const uint64_t launches = c->stats.intersect_launches;
     c->timing = false;
+    // the per-depth ray counters are cumulative: take this run's share as a difference and put the old values back
+    unsigned long long before[PRT_MAX_DEPTH], after[PRT_MAX_DEPTH];
+    HIPCHECK(c, hipMemcpy(before, c->d_ray_stats, sizeof(before), hipMemcpyDeviceToHost));
     rc = run_batch(c, 1, max_depth, seed, sample, false, c->d_trav_stats);
     c->timing = timing;
     c->stats.intersect_launches = launches;
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipMemcpy(after, c->d_ray_stats, sizeof(after), hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice));
     unsigned long long t[8];
     std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
@@ -867,11 +875,9 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     memset(out, 0, sizeof(*out));
     uint64_t front = 0;
     for (uint32_t d = 0; d < max_depth; ++d) {
-        const uint64_t n = (uint64_t)cnt[(size_t)d * PRT_CNT_STRIDE] + cnt[(size_t)d * PRT_CNT_STRIDE + 32] +
-                           cnt[(size_t)d * PRT_CNT_STRIDE + 16];  // front + back + finished in the producer
-        front += cnt[(size_t)d * PRT_CNT_STRIDE];
-        out->rays_per_depth[d] = n;
-        out->rays_total += n;
+        front += cnt[(size_t)d * PRT_CNT_STRIDE];  // rays handed to the traversal kernel in bounce iteration d
+        out->rays_per_depth[d] = after[d] - before[d];
+        out->rays_total += out->rays_per_depth[d];
     }
     out->rays_traversed = front;
     out->samples = 1;
@@ -922,6 +928,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;
     else if (n == "tri_min" && value >= 1 && value <= 1024) c->tune.tri_min = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;
     else if (n == "exit_max" && value >= 0 && value < 64) c->tune.exit_max = (uint32_t)value;

@@ -100,48 +100,122 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 __device__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0);
 __device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, f3& L);
 
+// Fused analytic segments.  A ray that cannot hit a triangle (it does not enter the BVH root box before its closest
+// analytic hit) is fully determined by the producer's own scan, so the producer shades it in place and goes on with
+// the scattered ray, FUSE segments per kernel call: such rays are never stored or re-read (C3: 62 % of all segments).
+// FUSE is a compile-time 0 or 1 and the steps are straight-line code: as a run-time loop the same body needs 94 instead
+// of 63 VGPRs (loop-invariant operand copies stay live across the back edge), which halves the occupancy of these
+// memory-bound kernels and costs more than the fusion saves (measured); one fused segment already gives all of the
+// gain (shade 14.6 -> 9.9 ms per 128 spp; a second one changes nothing).  Paths therefore advance by different numbers of segments per bounce iteration; every stored ray
+// carries its own segment index (depth) in throughput.w, and every path records the index of its LAST segment in
+// rad.w when it ends: k_accumulate derives the per-depth ray counts from those (segments at depth d = paths whose
+// last segment index is >= d), so the producers count nothing.
+//   returns 0: the path ended here (rad written)   1: (o, d) must be traversed (front)
+//           2: budget used up, (o, d) is stored with its known analytic hit id0 (back)
+// ONE loop serves both producers: on entry `id` is the final closest hit of segment `depth` = (o, d) over all
+// primitives (from the traversal kernel in k_shade, from the primary ray's classification in k_raygen); `budget` is
+// the number of segments this call may shade (k_shade: 1 + FUSE, k_raygen: FUSE).
+template <int BUDGET>
+PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr, uint32_t& rng, uint32_t& depth,
+                         uint32_t max_depth, float4* __restrict__ rad_slot, uint32_t& id0, float& d2_0) {
+#pragma unroll
+    for (int it = 0; it <= BUDGET; ++it) {
+        if (id == HIT_MISS) {  // the miss branch of IntersectClosestKernel, renderer.cu:263-271
+            const f3 L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);
+            *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+            return 0;
+        }
+        if (it == BUDGET) {  // only reached with an analytic id (the ray was classified "cannot hit a triangle")
+            const uint32_t m = sc.prims[id].material;
+            if (sc.mat_type[m] == 4u) {  // emissive: never scatters (material.h:119-122): the path stops here
+                const float4 e = sc.mat_rgbs[m];
+                const f3 L = thr * mk3(e.x, e.y, e.z);
+                *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+                return 0;
+            }
+            id0 = id;
+            return 2;
+        }
+        WorldHit w;
+        world_hit_from_id(sc, id, o, d, w);
+        const uint32_t type = sc.mat_type[w.material];
+        const float4 rgbs = sc.mat_rgbs[w.material];
+        f3 atten, emitted, so, sd;
+        bool scattered = false;
+        if (depth + 1u >= max_depth) {
+            emitted = (type == 4u) ? mk3(rgbs.x, rgbs.y, rgbs.z) : mk3(0.f, 0.f, 0.f);
+        } else {
+            scattered = material_scatter(type, rgbs, d, w.pos, w.normal, w.front, rng, atten, emitted, so, sd);
+        }
+        if (!scattered) {
+            const f3 L = thr * emitted;
+            *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+            return 0;
+        }
+        thr = thr * atten;
+        o = so;
+        d = normalize3(sd);  // scatteredRay.Normalize(), cpu/renderer.cpp:84
+        ++depth;
+        if (classify_ray(sc, o, d, id0, d2_0)) return 1;
+        id = id0;
+    }
+    return 2;  // not reached
+}
+
 // All S samples of a pixel start with the same pixel-centre ray (no jitter: cpu/renderer.cpp:45), so one thread
 // computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
 // seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
 #define RAYGEN_GROUP 8
+template <int FUSE>
 __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t S,
                                                             uint32_t first_sample, uint32_t seed,
                                                             float4* __restrict__ ro, float4* __restrict__ rd,
                                                             float4* __restrict__ rt, uint32_t* __restrict__ hit,
                                                             float* __restrict__ hd2, float4* __restrict__ rad,
-                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ work) {
+                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ work,
+                                                            uint32_t max_depth) {
     const uint32_t pl = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
     if (blockIdx.y == 0 && pl < 8u) work[32u * pl] = 0u;  // chunk cursors of the traversal kernel that follows
     if (blockIdx.y == 0 && pl == 8u) work[512] = 0u;      // its overflow-list counter
     const uint32_t n_paths = S * tm.n_pix_local;
     const bool in_range = pl < tm.n_pix_local;
-    bool valid = false, front = false, done = false;
-    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), L = mk3(0.f, 0.f, 0.f);
-    uint32_t id0 = HIT_MISS, pixel = 0;
-    float d2_0 = 3.402823466e+38f;
+    bool valid = false, front0 = false;
+    f3 o0 = mk3(0.f, 0.f, 0.f), d0 = mk3(0.f, 0.f, 1.f);
+    uint32_t id00 = HIT_MISS, pixel = 0;
+    float d2_00 = 3.402823466e+38f;
     if (in_range) {
         uint32_t x, y;
         valid = tile_pixel(tm, pl, x, y);
         if (valid) {
             pixel = y * tm.W + x;
-            camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);
-            front = classify_ray(sc, o, d, id0, d2_0);
-            done = ends_here(sc, front, id0, mk3(1.f, 1.f, 1.f), L);
+            camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o0, d0);
+            front0 = classify_ray(sc, o0, d0, id00, d2_00);
         }
     }
-    const bool back = valid && !front && !done;
     const uint32_t s0 = blockIdx.y * (uint32_t)RAYGEN_GROUP;
     const uint32_t s1 = (s0 + RAYGEN_GROUP < S) ? s0 + RAYGEN_GROUP : S;
     for (uint32_t sl = s0; sl < s1; ++sl) {  // block-uniform trip count
         const uint32_t i = sl * tm.n_pix_local + pl;  // path id
-        // paths that end here (sky / light seen directly) and lanes of partial tiles outside the image: rad only
-        if (in_range && (!valid || done)) rad[i] = make_float4(L.x, L.y, L.z, 0.f);
-        const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
+        f3 o = o0, d = d0, thr = mk3(1.f, 1.f, 1.f);
+        uint32_t rng = 0, depth = 0, id0 = id00;
+        float d2_0 = d2_00;
+        bool front = false, back = false;
+        if (valid) {
+            rng = path_seed(pixel, first_sample + sl, seed);
+            front = front0;
+            if (!front) {
+                const int r = advance_path<FUSE>(sc, id00, o, d, thr, rng, depth, max_depth, &rad[i], id0, d2_0);
+                front = r == 1;
+                back = r == 2;
+            }
+        } else if (in_range) {
+            rad[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // partial tiles outside the image: no path
+        }
+        const uint32_t slot = block_alloc2(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
         if (slot != 0xFFFFFFFFu) {
-            const uint32_t rng = path_seed(pixel, first_sample + sl, seed);
             ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
             rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-            rt[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+            rt[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(depth));
             hit[slot] = id0;
             hd2[slot] = d2_0;
         }
@@ -1431,23 +1505,24 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
 #define SHADE_BLOCK PRODUCER_BLOCK
+template <int FUSE>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
                                                       float4* __restrict__ nd, float4* __restrict__ nt,
                                                       uint32_t* __restrict__ nhit, float* __restrict__ nhd2,
                                                       float4* __restrict__ rad, uint32_t* __restrict__ counts,
-                                                      uint32_t* __restrict__ work, uint32_t depth, uint32_t max_depth,
+                                                      uint32_t* __restrict__ work, uint32_t iter, uint32_t max_depth,
                                                       uint32_t cap) {
-    const uint32_t nA = CNT_A(counts, depth), nB = CNT_B(counts, depth);
+    const uint32_t nA = CNT_A(counts, iter), nB = CNT_B(counts, iter);
     const uint32_t count = nA + nB;
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // whole block exits together
     const uint32_t k = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
     if (k < 8u) work[32u * k] = 0u;  // chunk cursors of the next bounce's traversal kernel
     if (k == 8u) work[512] = 0u;     // its overflow-list counter
-    bool front = false, back = false, done = false;
-    float4 O2, D2, T2;
-    uint32_t id0 = HIT_MISS;
+    bool front = false, back = false;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), thr = mk3(0.f, 0.f, 0.f);
+    uint32_t id0 = HIT_MISS, rng = 0, depth = 0, pid = 0;
     float d2_0 = 3.402823466e+38f;
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
@@ -1455,48 +1530,24 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
         const float4 D = rd[src];
         const float4 T = rt[src];
         const uint32_t id = hit[src];
-        const uint32_t pid = __float_as_uint(O.w);
-        uint32_t rng = __float_as_uint(D.w);
-        const f3 thr = mk3(T.x, T.y, T.z);
-        if (id == HIT_MISS) {
-            const f3 L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);
-            rad[pid] = make_float4(L.x, L.y, L.z, 0.f);
-        } else if (id != HIT_DEAD) {
-            const f3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
-            WorldHit w;
-            world_hit_from_id(sc, id, o, d, w);
-            const uint32_t type = sc.mat_type[w.material];
-            const float4 rgbs = sc.mat_rgbs[w.material];
-            f3 atten, emitted, so, sd;
-            bool scattered = false;
-            if (depth + 1u >= max_depth) {
-                emitted = (type == 4u) ? mk3(rgbs.x, rgbs.y, rgbs.z) : mk3(0.f, 0.f, 0.f);
-            } else {
-                scattered = material_scatter(type, rgbs, d, w.pos, w.normal, w.front, rng, atten, emitted, so, sd);
-            }
-            if (!scattered) {
-                const f3 L = thr * emitted;
-                rad[pid] = make_float4(L.x, L.y, L.z, 0.f);
-            } else {
-                const f3 t2 = thr * atten;
-                const f3 d2 = normalize3(sd);  // scatteredRay.Normalize(), cpu/renderer.cpp:84
-                O2 = make_float4(so.x, so.y, so.z, O.w);
-                D2 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(rng));
-                T2 = make_float4(t2.x, t2.y, t2.z, 0.f);
-                front = classify_ray(sc, so, d2, id0, d2_0);
-                f3 L2;
-                done = ends_here(sc, front, id0, t2, L2);
-                if (done) rad[pid] = make_float4(L2.x, L2.y, L2.z, 0.f);
-                back = !front && !done;
-            }
+        pid = __float_as_uint(O.w);
+        rng = __float_as_uint(D.w);
+        depth = __float_as_uint(T.w);  // segment index of this ray (paths advance at different rates, see advance_path)
+        thr = mk3(T.x, T.y, T.z);
+        if (id != HIT_DEAD) {
+            o = mk3(O.x, O.y, O.z);
+            d = mk3(D.x, D.y, D.z);
+            const int r = advance_path<1 + FUSE>(sc, id, o, d, thr, rng, depth, max_depth, &rad[pid], id0, d2_0);
+            front = r == 1;
+            back = r == 2;
         }
     }
-    const uint32_t slot = block_alloc2(front, back, done, &CNT_A(counts, depth + 1u), &CNT_B(counts, depth + 1u),
-                                       &CNT_C(counts, depth + 1u), cap);
+    const uint32_t slot = block_alloc2(front, back, false, &CNT_A(counts, iter + 1u), &CNT_B(counts, iter + 1u),
+                                       &CNT_C(counts, iter + 1u), cap);
     if (slot != 0xFFFFFFFFu) {
-        no[slot] = O2;
-        nd[slot] = D2;
-        nt[slot] = T2;
+        no[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
+        nd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
+        nt[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(depth));
         nhit[slot] = id0;
         nhd2[slot] = d2_0;
     }
@@ -1508,26 +1559,41 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
 // film_local is tile-ordered [n_pix_local] float4 {r_sum, g_sum, b_sum, weight}.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ rad, float4* __restrict__ film_local,
-                                                    PrtTileMap tm, uint32_t S, const uint32_t* __restrict__ counts,
-                                                    uint32_t max_depth, unsigned long long* __restrict__ ray_stats) {
+                                                    PrtTileMap tm, uint32_t S, uint32_t max_depth, int update_film,
+                                                    unsigned long long* __restrict__ ray_stats) {
+    // rad[path] = {radiance, index of the path's last segment}.  Ray segments at depth d = paths whose last segment
+    // index is >= d: a per-block histogram of the last indices (wave ballots -> LDS) gives the per-depth counts.
+    __shared__ uint32_t s_ends[PRT_MAX_DEPTH];
+    if (threadIdx.x < PRT_MAX_DEPTH) s_ends[threadIdx.x] = 0u;
+    __syncthreads();
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
-    if (pl == 0) {
-        for (uint32_t d = 0; d < max_depth; ++d)
-            ray_stats[d] += (unsigned long long)CNT_A(counts, d) + CNT_B(counts, d) + CNT_C(counts, d);
-    }
-    if (pl >= tm.n_pix_local) return;
     uint32_t x, y;
-    if (!tile_pixel(tm, pl, x, y)) return;
-    float4 f = film_local[pl];
+    const bool valid = pl < tm.n_pix_local && tile_pixel(tm, pl, x, y);
+    float4 f = valid ? film_local[pl] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float weight = 1.0f;
-    for (uint32_t s = 0; s < S; ++s) {
-        const float4 r = rad[(size_t)s * tm.n_pix_local + pl];
-        f.x += r.x * weight;
-        f.y += r.y * weight;
-        f.z += r.z * weight;
-        f.w += weight;
+    const uint32_t lane = lane_id();
+    for (uint32_t s = 0; s < S; ++s) {  // block-uniform trip count
+        uint32_t e = 0xFFFFFFFFu;
+        if (valid) {
+            const float4 r = rad[(size_t)s * tm.n_pix_local + pl];
+            f.x += r.x * weight;
+            f.y += r.y * weight;
+            f.z += r.z * weight;
+            f.w += weight;
+            e = __float_as_uint(r.w);
+        }
+        for (uint32_t dd = 0; dd < max_depth; ++dd) {
+            const unsigned long long mk = __ballot(e == dd);
+            if (mk != 0ull && lane == 0) atomicAdd(&s_ends[dd], (uint32_t)__popcll(mk));
+        }
     }
-    film_local[pl] = f;
+    if (valid && update_film) film_local[pl] = f;
+    __syncthreads();
+    if (threadIdx.x < max_depth) {
+        unsigned long long n = 0;
+        for (uint32_t e = threadIdx.x; e < max_depth; ++e) n += s_ends[e];
+        if (n) atomicAdd(&ray_stats[threadIdx.x], n);
+    }
 }
 
 // Un-tile `world` gathered rank payloads (each `stride` float4) into the Film layout
@@ -1669,11 +1735,15 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 2
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t* work) {
+                       uint32_t* work, uint32_t max_depth, uint32_t fuse_max) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
     const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
-    hipLaunchKernelGGL(k_raygen, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o, out.d,
-                       out.t, out.hit, out.hd2, rad, counts, work);
+    if (fuse_max)
+        hipLaunchKernelGGL(k_raygen<1>, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o,
+                           out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth);
+    else
+        hipLaunchKernelGGL(k_raygen<0>, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o,
+                           out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth);
 }
 
 void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
@@ -1778,16 +1848,21 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 }
 
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
-                      uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap) {
-    hipLaunchKernelGGL(k_shade, dim3((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc,
-                       in.o, in.d, in.t, in.hit, out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, depth,
-                       max_depth, cap);
+                      uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
+                      uint32_t fuse_max) {
+    const dim3 grid((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK));
+    if (fuse_max)
+        hipLaunchKernelGGL(k_shade<1>, grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d, out.t,
+                           out.hit, out.hd2, rad, counts, work, depth, max_depth, cap);
+    else
+        hipLaunchKernelGGL(k_shade<0>, grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d, out.t,
+                           out.hit, out.hd2, rad, counts, work, depth, max_depth, cap);
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
-                           const uint32_t* counts, uint32_t max_depth, unsigned long long* ray_stats) {
+                           uint32_t max_depth, bool update_film, unsigned long long* ray_stats) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(tm.n_pix_local ? tm.n_pix_local : 1)), dim3(256), 0, st, rad,
-                       film_local, tm, S, counts, max_depth, ray_stats);
+                       film_local, tm, S, max_depth, update_film ? 1 : 0, ray_stats);
 }
 
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,

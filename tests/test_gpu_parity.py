@@ -226,12 +226,15 @@ def test_image_parity_mesh_scene_vs_linear_scan_oracle():
     assert r.stats().rays_total == rays
 
 
-def test_image_parity_bunny_vs_oracle_bvh():
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_image_parity_bunny_vs_oracle_bvh(fuse):
+    """fuse = 1: the producers shade one analytic-only segment in place (paths advance at different rates)."""
     mesh = prt.scenes.refined("bunny.ply", 30_000)
     scene = prt.scenes.mesh_scene(mesh)
     W, H, spp, depth = 160, 90, 2, 5
     cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
     r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=8, cam=cam)
+    r.set_param("fuse", fuse)
     r.ProgressiveRender(spp)
     r.download()
     osc = util.oracle_scene(scene)
@@ -241,7 +244,9 @@ def test_image_parity_bunny_vs_oracle_bvh():
     acc_re, _, _ = osc.render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=8, iterative=False, use_bvh=True,
                               n_threads=8)
     assert util.image_l2(film.accum / spp, acc_re / spp) <= TOL_L2
-    assert r.stats().rays_total == rays
+    st = r.stats()
+    assert st.rays_total == rays and st.rays_per_depth[0] == spp * W * H
+    assert all(st.rays_per_depth[d] >= st.rays_per_depth[d + 1] for d in range(depth)) and st.rays_per_depth[depth] == 0
 
 
 def test_triangulated_quads_match_analytic_quads():
