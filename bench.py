@@ -38,7 +38,7 @@ MESH_OF = {"C2": "bunny.ply refined by longest-edge bisection", "C3": "dragon.pl
            "C4": "dragon.ply refined by longest-edge bisection", "C5": "12 baked copies of the refined dragon.ply"}
 
 
-def load_traffic(config, world, spp_step, sif):
+def load_traffic(config, world, spp_step, sif, kernel):
     import glob
     best = (None, "no committed PMC profile matches this configuration")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
@@ -47,7 +47,7 @@ def load_traffic(config, world, spp_step, sif):
         except Exception:
             continue
         # a launch = one bounce of one batch of `sif` samples over this rank's pixels, whatever the step length
-        if (t.get("config"), t.get("n_gpus"), t.get("samples_in_flight")) == (config, world, sif):
+        if (t.get("config"), t.get("n_gpus"), t.get("samples_in_flight"), t.get("kernel")) == (config, world, sif, kernel):
             best = (t.get("hbm_bytes_per_launch"), f"{os.path.basename(f)}: {t.get('note', '')}")
     return best
 
@@ -180,7 +180,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # measured HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (profiles/*_traffic.json, written by tools/pmc_traffic.py); null when no matching profile is committed
-        traffic, traffic_note = load_traffic(args.config, world, spp_step, sif)
+        traffic, traffic_note = load_traffic(args.config, world, spp_step, sif, kernel_name)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": kernel_name, "node_bytes": node_bytes,
