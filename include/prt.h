@@ -107,6 +107,19 @@ typedef struct PrtCameraDesc {
     float height;
 } PrtCameraDesc;
 
+/* Optional sampling upgrades; all zero = the reference CPU backend's behaviour.
+ *  jitter   1: the primary ray goes through (x + u1, y + u2), u1/u2 = the path's first two RNG draws (reference OptiX
+ *           backend, src/backend/optix/device_programs.cu:172-173); 0: pixel centres (src/backend/cpu/renderer.cpp:45).
+ *  rr_depth > 0: Russian roulette (reference roadmap, wavefront.md:98-100): a scatter that would start segment index
+ *           >= rr_depth survives with p = clamp(max component of the new throughput, 0.05, 1), one RNG draw after the
+ *           material's own; survivors carry throughput / p.
+ *  clamp    > 0: every component of the radiance a path delivers is limited to it (wavefront.md:102-104). */
+typedef struct PrtSampling {
+    uint32_t jitter;
+    uint32_t rr_depth;
+    float clamp;
+} PrtSampling;
+
 /* Closest-hit record of one ray (what Scene::Intersect returns, src/core/surface_interaction.h:6-13,
  * plus the winning primitive index and the world distance^2 the reference minimises,
  * src/core/primitive.cpp:42-48).  prim < 0: miss. */
@@ -185,6 +198,8 @@ int prt_render(PrtContext* ctx, uint32_t spp, uint32_t max_depth, uint32_t seed,
 /* Same, but only enqueues on the stream (no host sync). */
 int prt_render_async(PrtContext* ctx, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample);
 int prt_synchronize(PrtContext* ctx);
+/* Sampling upgrades for the following prt_render calls (NULL = all off). */
+int prt_set_sampling(PrtContext* ctx, const PrtSampling* sampling);
 /* Samples kept in flight together (paths = local pixels * n); default 1. */
 int prt_set_samples_in_flight(PrtContext* ctx, uint32_t n);
 

@@ -466,8 +466,29 @@ inline bool scatter(const PrtMaterial& m, V3 in_d, const SI& si, uint32_t* rng, 
     }
 }
 
-V3 trace_recursive(const OrcScene* s, V3 o, V3 d, int depth, uint32_t* rng, int use_bvh, uint32_t* segs) {
-    // CPURenderer::TraceRay (backend/cpu/renderer.cpp:59-103)
+// Optional sampling upgrades (PrtSampling, include/prt.h).  All off = the reference CPU backend.
+//  * jitter: the primary ray goes through (x + u1, y + u2), u1 and u2 being the path's first two RNG draws (the
+//    reference's OptiX backend, backend/optix/device_programs.cu:172-173); off: pixel centres (cpu/renderer.cpp:45).
+//  * Russian roulette (reference roadmap only, wavefront.md:98-100; the rule is this project's): when a scatter would
+//    start segment index >= rr_depth, the path survives with p = clamp(max component of the new throughput, 0.05, 1),
+//    decided by ONE draw u taken after the material's own draws (u >= p ends the path with nothing more added);
+//    survivors carry throughput / p.
+//  * clamp (wavefront.md:102-104): every component of the radiance a path delivers is limited to `clamp`.
+static inline bool rr_active(const PrtSampling* sp, int next_index) { return sp && sp->rr_depth && (uint32_t)next_index >= sp->rr_depth; }
+static inline float rr_prob(V3 thr) {
+    float p = thr.x > thr.y ? thr.x : thr.y;
+    p = p > thr.z ? p : thr.z;
+    p = p > 1.0f ? 1.0f : p;
+    return p < 0.05f ? 0.05f : p;
+}
+static inline V3 clamp_radiance(const PrtSampling* sp, V3 L) {
+    if (!sp || !(sp->clamp > 0.0f)) return L;
+    return v3(L.x > sp->clamp ? sp->clamp : L.x, L.y > sp->clamp ? sp->clamp : L.y, L.z > sp->clamp ? sp->clamp : L.z);
+}
+
+V3 trace_recursive_impl(const OrcScene* s, V3 o, V3 d, int depth, int index, V3 thr, uint32_t* rng, int use_bvh,
+                        uint32_t* segs, const PrtSampling* sp) {
+    // CPURenderer::TraceRay (backend/cpu/renderer.cpp:59-103); index / thr only feed the optional roulette
     if (depth <= 0) return v3(0, 0, 0);
     V3 L = v3(0, 0, 0);
     Best b;
@@ -480,7 +501,18 @@ V3 trace_recursive(const OrcScene* s, V3 o, V3 d, int depth, uint32_t* rng, int 
         bool sc = scatter(m, d, b.si, rng, &atten, &so, &sd);
         if (sc) {
             sd = normalize(sd);  // scatteredRay.Normalize() (:84)
-            L = L + atten * trace_recursive(s, so, sd, depth - 1, rng, use_bvh, segs);
+            V3 t2 = thr * atten;
+            float p = 1.0f;
+            bool alive = true;
+            if (depth > 1 && rr_active(sp, index + 1)) {
+                p = rr_prob(t2);
+                alive = rnd(rng) < p;
+                t2 = v3(t2.x / p, t2.y / p, t2.z / p);
+            }
+            if (alive) {
+                V3 Li = trace_recursive_impl(s, so, sd, depth - 1, index + 1, t2, rng, use_bvh, segs, sp);
+                L = L + atten * v3(Li.x / p, Li.y / p, Li.z / p);
+            }
         }
     } else {
         L = L + ld3(s->sky);
@@ -488,7 +520,13 @@ V3 trace_recursive(const OrcScene* s, V3 o, V3 d, int depth, uint32_t* rng, int 
     return L;
 }
 
-V3 trace_iterative(const OrcScene* s, V3 o, V3 d, int max_depth, uint32_t* rng, int use_bvh, uint32_t* segs) {
+V3 trace_recursive(const OrcScene* s, V3 o, V3 d, int depth, uint32_t* rng, int use_bvh, uint32_t* segs,
+                   const PrtSampling* sp = nullptr) {
+    return clamp_radiance(sp, trace_recursive_impl(s, o, d, depth, 0, v3(1, 1, 1), rng, use_bvh, segs, sp));
+}
+
+V3 trace_iterative(const OrcScene* s, V3 o, V3 d, int max_depth, uint32_t* rng, int use_bvh, uint32_t* segs,
+                   const PrtSampling* sp = nullptr) {
     // TraceRayGPU (backend/cuda_megakernel/renderer.cu:81-119)
     V3 L = v3(0, 0, 0);
     V3 thr = v3(1, 1, 1);
@@ -507,8 +545,13 @@ V3 trace_iterative(const OrcScene* s, V3 o, V3 d, int max_depth, uint32_t* rng, 
         thr = thr * atten;
         o = so;
         d = normalize(sd);
+        if (depth + 1 < max_depth && rr_active(sp, depth + 1)) {
+            const float p = rr_prob(thr);
+            if (!(rnd(rng) < p)) break;
+            thr = v3(thr.x / p, thr.y / p, thr.z / p);
+        }
     }
-    return L;
+    return clamp_radiance(sp, L);
 }
 
 struct Cam {
@@ -933,9 +976,21 @@ void orc_trace(const OrcScene* s, const float o[3], const float d[3], int max_de
     if (n_segments) *n_segments = segs;
 }
 
+void orc_render_sampling(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_t H, uint32_t x0, uint32_t y0,
+                         uint32_t x1, uint32_t y1, uint32_t spp, uint32_t first_sample, int max_depth, uint32_t seed,
+                         int iterative, int use_bvh, int n_threads, const PrtSampling* sp, float* accum, float* weights,
+                         uint64_t* rays);
 void orc_render(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_t H, uint32_t x0, uint32_t y0,
                 uint32_t x1, uint32_t y1, uint32_t spp, uint32_t first_sample, int max_depth, uint32_t seed,
                 int iterative, int use_bvh, int n_threads, float* accum, float* weights, uint64_t* rays) {
+    orc_render_sampling(s, cam, W, H, x0, y0, x1, y1, spp, first_sample, max_depth, seed, iterative, use_bvh, n_threads,
+                        nullptr, accum, weights, rays);
+}
+
+void orc_render_sampling(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_t H, uint32_t x0, uint32_t y0,
+                         uint32_t x1, uint32_t y1, uint32_t spp, uint32_t first_sample, int max_depth, uint32_t seed,
+                         int iterative, int use_bvh, int n_threads, const PrtSampling* sp, float* accum, float* weights,
+                         uint64_t* rays) {
     Cam c = make_cam(cam);
     x1 = std::min(x1, W);
     y1 = std::min(y1, H);
@@ -952,11 +1007,16 @@ void orc_render(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_
             const uint32_t idx = j * W + i;
             for (uint32_t sidx = first_sample; sidx < first_sample + spp; ++sidx) {
                 V3 o, d;
-                camera_ray(c, (float)i + 0.5f, (float)j + 0.5f, &o, &d);  // cpu/renderer.cpp:45
                 uint32_t rng = orc_path_seed(idx, sidx, seed);
+                float fx = 0.5f, fy = 0.5f;  // pixel centre, cpu/renderer.cpp:45
+                if (sp && sp->jitter) {      // backend/optix/device_programs.cu:172-173
+                    fx = rnd(&rng);
+                    fy = rnd(&rng);
+                }
+                camera_ray(c, (float)i + fx, (float)j + fy, &o, &d);
                 uint32_t segs = 0;
-                V3 L = iterative ? trace_iterative(s, o, d, max_depth, &rng, use_bvh, &segs)
-                                 : trace_recursive(s, o, d, max_depth, &rng, use_bvh, &segs);
+                V3 L = iterative ? trace_iterative(s, o, d, max_depth, &rng, use_bvh, &segs, sp)
+                                 : trace_recursive(s, o, d, max_depth, &rng, use_bvh, &segs, sp);
                 local += segs;
                 // Film::AddSample (film.cu:37-55), weight = 1
                 const float weight = 1.0f;

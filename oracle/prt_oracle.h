@@ -78,6 +78,12 @@ void orc_render(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_
                 uint32_t x1, uint32_t y1, uint32_t spp, uint32_t first_sample, int max_depth, uint32_t seed,
                 int iterative, int use_bvh, int n_threads, float* accum, float* weights, uint64_t* rays);
 
+/* The same with the optional sampling upgrades of PrtSampling (include/prt.h; NULL = orc_render). */
+void orc_render_sampling(const OrcScene* s, const PrtCameraDesc* cam, uint32_t W, uint32_t H, uint32_t x0, uint32_t y0,
+                         uint32_t x1, uint32_t y1, uint32_t spp, uint32_t first_sample, int max_depth, uint32_t seed,
+                         int iterative, int use_bvh, int n_threads, const PrtSampling* sp, float* accum, float* weights,
+                         uint64_t* rays);
+
 /* Film::UpdateDisplay (src/core/film.cu:134-194) */
 void orc_tonemap(const float* accum, const float* weights, uint32_t n_pixels, float exposure, float gamma,
                  uint8_t* rgba8);

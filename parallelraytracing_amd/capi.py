@@ -63,6 +63,10 @@ class PrtStats(C.Structure):
                 ("scan_ms", C.c_double), ("rays_traversed", C.c_uint64), ("tri_lane_slots", C.c_uint64), ("max_stack_used", C.c_uint64)]
 
 
+class PrtSampling(C.Structure):
+    _fields_ = [("jitter", C.c_uint32), ("rr_depth", C.c_uint32), ("clamp", C.c_float)]
+
+
 class PrtBvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("max_depth", C.c_uint32),
                 ("max_leaf_size", C.c_uint32), ("sah_cost", C.c_float), ("pad_abs", C.c_float),
@@ -108,6 +112,7 @@ SIGNATURES = {
     "prt_measure_traversal": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PrtStats)]),
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
+    "prt_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),
     "prt_bvh_read4": (C.c_int, [_vp, _fp]),
     "prt_bvh_read8": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "prt_set_variant": (C.c_int, [_vp, C.c_int]),

@@ -88,6 +88,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
+    PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
     PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u};
@@ -274,16 +275,16 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     if (rc) return rc;
     const int stack_depth = c->bvh.max_depth <= 31 ? 31 : 63;
     if ((rc = ensure_spill(c))) return rc;
-    // A/B option (off by default, measured 11 % slower on C3: the fused producers need 78 / 119 VGPRs instead of 64 /
-    // 72 and lose more to occupancy than they save in ray traffic): analytic-only segments shaded inside the
-    // producers, only when the scene has a BVH and few analytic primitives
+    // k_shade shades one analytic-only segment in place per call (never stored, never re-read: shade -24 % on C3) when
+    // the scene has a BVH and few analytic primitives; with many of them (RANDOM_BALLS presets) compacting between
+    // bounces is the better deal
     const uint32_t fuse = (c->dsc.n_nodes && c->dsc.n_prims <= 16u) ? c->tune.fuse : 0u;
     EventPair ep{};
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
     if ((rc = begin_event(c, 0, &ep))) return rc;
     prt_launch_raygen(c->stream, c->dsc, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts,
-                      c->d_work, max_depth, fuse);
+                      c->d_work, max_depth, c->sampling);
     if ((rc = end_event(c, &ep))) return rc;
     for (uint32_t d = 0; d < max_depth; ++d) {
         const PrtRayBuf& in = c->rb[d & 1];
@@ -300,7 +301,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             ++c->stats.intersect_launches;
         }
         if ((rc = begin_event(c, 2, &ep))) return rc;
-        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse);
+        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling);
         if ((rc = end_event(c, &ep))) return rc;
     }
     // film += the batch's samples (unless this is a measurement run) and per-depth ray counts from the paths' last
@@ -583,6 +584,14 @@ int prt_film_clear(PrtContext* c) {
     if (!c->has_film) return fail(c, PRT_ERR_INVALID, "prt_set_film has not been called");
     HIPCHECK(c, hipMemsetAsync(c->d_film_local, 0, std::max<size_t>((size_t)c->tm.stride, 64) * sizeof(float4), c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_set_sampling(PrtContext* c, const PrtSampling* sp) {
+    if (!c) return PRT_ERR_INVALID;
+    if (sp && (sp->jitter > 1u || sp->rr_depth > PRT_MAX_DEPTH || !(sp->clamp >= 0.0f)))
+        return fail(c, PRT_ERR_INVALID, "bad sampling options");
+    c->sampling = sp ? *sp : PrtSampling{0u, 0u, 0.0f};
     return PRT_OK;
 }
 

@@ -58,7 +58,7 @@ struct PrtTravTuning {
     uint32_t xcd_affinity; // 1: each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
     uint32_t wide;         // 2: walk the compressed 8-wide tree (default), 1: the 4-wide tree, 0: the binary tree
     uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles
-    uint32_t fuse;         // producers: 1 = shade one analytic-only segment in place per kernel call, 0 = store every ray
+    uint32_t fuse;         // k_shade: 1 = shade one analytic-only segment in place per call (default), 0 = store every ray
     uint32_t stack_lds;    // selects the kernel instance (stack entries in LDS / waves per SIMD), see prt_launch_traverse
 };
 
@@ -74,7 +74,7 @@ struct PrtRayBuf {
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t* work, uint32_t max_depth, uint32_t fuse_max);
+                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp);
 void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                            uint32_t* work, uint32_t max_rays, unsigned long long* stats);
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
@@ -84,7 +84,7 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
                           uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max);
+                      uint32_t fuse_max, const PrtSampling& sp);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats);
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,

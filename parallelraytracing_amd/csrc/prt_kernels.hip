@@ -39,15 +39,17 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 #define CNT_A(c, d) (c)[(d) * CNT_STRIDE]
 #define CNT_B(c, d) (c)[(d) * CNT_STRIDE + 32u]
 #define CNT_C(c, d) (c)[(d) * CNT_STRIDE + 16u]
-#define PRODUCER_BLOCK 1024
+#define PRODUCER_BLOCK 1024  // k_raygen
+#define SHADE_BLOCK 512      // k_shade: its variants with 82 SGPRs / 78 VGPRs keep 6 waves per SIMD this way (1024: 4)
 
-// Slot reservation for a 1024-thread block with ONE atomic per side (a counter word sustains only ~88
+// Slot reservation for a BLOCK-thread block with ONE atomic per side (a counter word sustains only ~88
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
 // reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
 // Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
+template <int BLOCK>
 PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, uint32_t* cntB, uint32_t* cntC,
                               uint32_t cap) {
-    __shared__ uint32_t s_a[PRODUCER_BLOCK / 64], s_b[PRODUCER_BLOCK / 64], s_c[PRODUCER_BLOCK / 64];
+    __shared__ uint32_t s_a[BLOCK / 64], s_b[BLOCK / 64], s_c[BLOCK / 64];
     __shared__ uint32_t s_base_a, s_base_b;
     const unsigned long long ma = __ballot(front), mb = __ballot(back), mc = __ballot(done);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -59,7 +61,7 @@ PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, 
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t ta = 0, tb = 0, tc = 0;
-        for (uint32_t w = 0; w < PRODUCER_BLOCK / 64; ++w) {
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) {
             ta += s_a[w];
             tb += s_b[w];
             tc += s_c[w];
@@ -106,7 +108,10 @@ __device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, 
 // FUSE is a compile-time 0 or 1 and the steps are straight-line code: as a run-time loop the same body needs 94 instead
 // of 63 VGPRs (loop-invariant operand copies stay live across the back edge), which halves the occupancy of these
 // memory-bound kernels and costs more than the fusion saves (measured); one fused segment already gives all of the
-// gain (shade 14.6 -> 9.9 ms per 128 spp; a second one changes nothing).  Paths therefore advance by different numbers of segments per bounce iteration; every stored ray
+// gain (a second one changes nothing).  k_shade fuses (512-thread blocks: 78 VGPRs / 82 SGPRs = 6 waves per SIMD;
+// shade 76 -> 57 ms per 1024 spp on C3); k_raygen does not (its 8-samples-per-thread loop around the shading body needs
+// 119 VGPRs and ran 2.4x slower fused): a primary ray that cannot hit a triangle is stored on the back side and
+// continued by the first k_shade.  Paths therefore advance by different numbers of segments per bounce iteration; every stored ray
 // carries its own segment index (depth) in throughput.w, and every path records the index of its LAST segment in
 // rad.w when it ends: k_accumulate derives the per-depth ray counts from those (segments at depth d = paths whose
 // last segment index is >= d), so the producers count nothing.
@@ -115,22 +120,31 @@ __device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, 
 // ONE loop serves both producers: on entry `id` is the final closest hit of segment `depth` = (o, d) over all
 // primitives (from the traversal kernel in k_shade, from the primary ray's classification in k_raygen); `budget` is
 // the number of segments this call may shade (k_shade: 1 + FUSE, k_raygen: FUSE).
+// Radiance a path delivers, with the optional firefly clamp (PrtSampling.clamp; 0 = off).
+PRT_DEV float4 path_result(f3 L, float clamp, uint32_t depth) {
+    if (clamp > 0.0f) {
+        L.x = L.x > clamp ? clamp : L.x;
+        L.y = L.y > clamp ? clamp : L.y;
+        L.z = L.z > clamp ? clamp : L.z;
+    }
+    return make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+}
+
 template <int BUDGET>
 PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr, uint32_t& rng, uint32_t& depth,
-                         uint32_t max_depth, float4* __restrict__ rad_slot, uint32_t& id0, float& d2_0) {
+                         uint32_t max_depth, const PrtSampling& sp, float4* __restrict__ rad_slot, uint32_t& id0,
+                         float& d2_0) {
 #pragma unroll
     for (int it = 0; it <= BUDGET; ++it) {
         if (id == HIT_MISS) {  // the miss branch of IntersectClosestKernel, renderer.cu:263-271
-            const f3 L = thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]);
-            *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+            *rad_slot = path_result(thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]), sp.clamp, depth);
             return 0;
         }
         if (it == BUDGET) {  // only reached with an analytic id (the ray was classified "cannot hit a triangle")
             const uint32_t m = sc.prims[id].material;
             if (sc.mat_type[m] == 4u) {  // emissive: never scatters (material.h:119-122): the path stops here
                 const float4 e = sc.mat_rgbs[m];
-                const f3 L = thr * mk3(e.x, e.y, e.z);
-                *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+                *rad_slot = path_result(thr * mk3(e.x, e.y, e.z), sp.clamp, depth);
                 return 0;
             }
             id0 = id;
@@ -148,13 +162,23 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             scattered = material_scatter(type, rgbs, d, w.pos, w.normal, w.front, rng, atten, emitted, so, sd);
         }
         if (!scattered) {
-            const f3 L = thr * emitted;
-            *rad_slot = make_float4(L.x, L.y, L.z, __uint_as_float(depth));
+            *rad_slot = path_result(thr * emitted, sp.clamp, depth);
             return 0;
         }
         thr = thr * atten;
         o = so;
         d = normalize3(sd);  // scatteredRay.Normalize(), cpu/renderer.cpp:84
+        if (sp.rr_depth != 0u && depth + 1u >= sp.rr_depth) {  // Russian roulette (PrtSampling, include/prt.h)
+            float p = thr.x > thr.y ? thr.x : thr.y;
+            p = p > thr.z ? p : thr.z;
+            p = p > 1.0f ? 1.0f : p;
+            p = p < 0.05f ? 0.05f : p;
+            if (!(rnd01(rng) < p)) {
+                *rad_slot = path_result(mk3(0.f, 0.f, 0.f), 0.0f, depth);
+                return 0;
+            }
+            thr = mk3(thr.x / p, thr.y / p, thr.z / p);
+        }
         ++depth;
         if (classify_ray(sc, o, d, id0, d2_0)) return 1;
         id = id0;
@@ -166,14 +190,17 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 // computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
 // seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
 #define RAYGEN_GROUP 8
-template <int FUSE>
+// SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
+// which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
+template <bool JITTER, bool SAMPLING>
 __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t S,
                                                             uint32_t first_sample, uint32_t seed,
                                                             float4* __restrict__ ro, float4* __restrict__ rd,
                                                             float4* __restrict__ rt, uint32_t* __restrict__ hit,
                                                             float* __restrict__ hd2, float4* __restrict__ rad,
                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ work,
-                                                            uint32_t max_depth) {
+                                                            uint32_t max_depth, PrtSampling sp_arg) {
+    const PrtSampling sp = SAMPLING ? sp_arg : PrtSampling{0u, 0u, 0.0f};
     const uint32_t pl = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
     if (blockIdx.y == 0 && pl < 8u) work[32u * pl] = 0u;  // chunk cursors of the traversal kernel that follows
     if (blockIdx.y == 0 && pl == 8u) work[512] = 0u;      // its overflow-list counter
@@ -181,15 +208,16 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
     const bool in_range = pl < tm.n_pix_local;
     bool valid = false, front0 = false;
     f3 o0 = mk3(0.f, 0.f, 0.f), d0 = mk3(0.f, 0.f, 1.f);
-    uint32_t id00 = HIT_MISS, pixel = 0;
+    uint32_t id00 = HIT_MISS, pixel = 0, px = 0, py = 0;
     float d2_00 = 3.402823466e+38f;
     if (in_range) {
-        uint32_t x, y;
-        valid = tile_pixel(tm, pl, x, y);
+        valid = tile_pixel(tm, pl, px, py);
         if (valid) {
-            pixel = y * tm.W + x;
-            camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o0, d0);
-            front0 = classify_ray(sc, o0, d0, id00, d2_00);
+            pixel = py * tm.W + px;
+            if (!JITTER) {  // pixel centre, the same ray for every sample (cpu/renderer.cpp:45)
+                camera_ray(cam, (float)px + 0.5f, (float)py + 0.5f, o0, d0);
+                front0 = classify_ray(sc, o0, d0, id00, d2_00);
+            }
         }
     }
     const uint32_t s0 = blockIdx.y * (uint32_t)RAYGEN_GROUP;
@@ -203,15 +231,21 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         if (valid) {
             rng = path_seed(pixel, first_sample + sl, seed);
             front = front0;
+            if (JITTER) {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
+                const float u1 = rnd01(rng);
+                const float u2 = rnd01(rng);
+                camera_ray(cam, (float)px + u1, (float)py + u2, o, d);
+                front = classify_ray(sc, o, d, id0, d2_0);
+            }
             if (!front) {
-                const int r = advance_path<FUSE>(sc, id00, o, d, thr, rng, depth, max_depth, &rad[i], id0, d2_0);
+                const int r = advance_path<0>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
                 front = r == 1;
                 back = r == 2;
             }
         } else if (in_range) {
             rad[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // partial tiles outside the image: no path
         }
-        const uint32_t slot = block_alloc2(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
+        const uint32_t slot = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
         if (slot != 0xFFFFFFFFu) {
             ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
             rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
@@ -1504,8 +1538,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-#define SHADE_BLOCK PRODUCER_BLOCK
-template <int FUSE>
+template <int FUSE, bool SAMPLING>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
@@ -1513,7 +1546,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
                                                       uint32_t* __restrict__ nhit, float* __restrict__ nhd2,
                                                       float4* __restrict__ rad, uint32_t* __restrict__ counts,
                                                       uint32_t* __restrict__ work, uint32_t iter, uint32_t max_depth,
-                                                      uint32_t cap) {
+                                                      uint32_t cap, PrtSampling sp_arg) {
+    const PrtSampling sp = SAMPLING ? sp_arg : PrtSampling{0u, 0u, 0.0f};
     const uint32_t nA = CNT_A(counts, iter), nB = CNT_B(counts, iter);
     const uint32_t count = nA + nB;
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // whole block exits together
@@ -1537,13 +1571,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
         if (id != HIT_DEAD) {
             o = mk3(O.x, O.y, O.z);
             d = mk3(D.x, D.y, D.z);
-            const int r = advance_path<1 + FUSE>(sc, id, o, d, thr, rng, depth, max_depth, &rad[pid], id0, d2_0);
+            const int r = advance_path<1 + FUSE>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
             front = r == 1;
             back = r == 2;
         }
     }
-    const uint32_t slot = block_alloc2(front, back, false, &CNT_A(counts, iter + 1u), &CNT_B(counts, iter + 1u),
-                                       &CNT_C(counts, iter + 1u), cap);
+    const uint32_t slot = block_alloc2<SHADE_BLOCK>(front, back, false, &CNT_A(counts, iter + 1u), &CNT_B(counts, iter + 1u),
+                                                    &CNT_C(counts, iter + 1u), cap);
     if (slot != 0xFFFFFFFFu) {
         no[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
         nd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
@@ -1735,15 +1769,19 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 2
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t* work, uint32_t max_depth, uint32_t fuse_max) {
+                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
     const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
-    if (fuse_max)
-        hipLaunchKernelGGL(k_raygen<1>, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o,
-                           out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth);
-    else
-        hipLaunchKernelGGL(k_raygen<0>, grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o,
-                           out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth);
+#define PRT_RAYGEN(J, SA)                                                                                           \
+    hipLaunchKernelGGL((k_raygen<J, SA>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o, \
+                       out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp)
+    const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
+    if (sp.jitter) {
+        if (sa) PRT_RAYGEN(true, true); else PRT_RAYGEN(true, false);
+    } else {
+        if (sa) PRT_RAYGEN(false, true); else PRT_RAYGEN(false, false);
+    }
+#undef PRT_RAYGEN
 }
 
 void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
@@ -1849,14 +1887,18 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max) {
+                      uint32_t fuse_max, const PrtSampling& sp) {
     const dim3 grid((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK));
-    if (fuse_max)
-        hipLaunchKernelGGL(k_shade<1>, grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d, out.t,
-                           out.hit, out.hd2, rad, counts, work, depth, max_depth, cap);
-    else
-        hipLaunchKernelGGL(k_shade<0>, grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d, out.t,
-                           out.hit, out.hd2, rad, counts, work, depth, max_depth, cap);
+#define PRT_SHADE(F, SA)                                                                                            \
+    hipLaunchKernelGGL((k_shade<F, SA>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d,  \
+                       out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
+    const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
+    if (fuse_max) {
+        if (sa) PRT_SHADE(1, true); else PRT_SHADE(1, false);
+    } else {
+        if (sa) PRT_SHADE(0, true); else PRT_SHADE(0, false);
+    }
+#undef PRT_SHADE
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,

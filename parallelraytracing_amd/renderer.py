@@ -17,7 +17,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import capi
-from .capi import (PrtBvhInfo, PrtCameraDesc, PrtHit, PrtMaterial, PrtMesh, PrtPrimitive, PrtSceneDesc, PrtStats)
+from .capi import (PrtBvhInfo, PrtCameraDesc, PrtHit, PrtMaterial, PrtMesh, PrtPrimitive, PrtSampling, PrtSceneDesc,
+                   PrtStats)
 
 _fp = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)
@@ -322,6 +323,12 @@ class HipWavefrontRenderer:
 
     def set_samples_in_flight(self, n: int):
         self._check(capi.lib().prt_set_samples_in_flight(self._ctx, n))
+
+    def set_sampling(self, jitter: int = 0, rr_depth: int = 0, clamp: float = 0.0) -> PrtSampling:
+        """Optional sampling upgrades (include/prt.h PrtSampling); all zero = the reference CPU backend."""
+        sp = PrtSampling(int(jitter), int(rr_depth), float(clamp))
+        self._check(capi.lib().prt_set_sampling(self._ctx, C.byref(sp)))
+        return sp
 
     def set_variant(self, v: int):
         self._check(capi.lib().prt_set_variant(self._ctx, v))

@@ -355,6 +355,26 @@ def test_bvh_python_traversal_agrees_with_oracle_linear_scan():
         assert int(want["prim"][k]) in reached
 
 
+# ---- the C++ host side above the C-ABI (parallelraytracing_amd/host) ------------------------------------------------------
+def test_cpp_adapter_cli_builds_and_fails_loudly_without_a_device(tmp_path):
+    """prt_render = the reference-shaped C++ adapter (Scene / Camera / Film / HipWavefrontRenderer over prt.h) plus the
+    offline framebuffer dump.  It must build with g++ against the header alone and, on a box without a GPU, stop with
+    an error instead of producing an image."""
+    import subprocess
+    import torch
+    import __graft_entry__ as g
+    g.build(quiet=True)
+    exe = os.path.join(util.ROOT, "parallelraytracing_amd", "csrc", "prt_render")
+    assert os.path.exists(exe)
+    p = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert p.returncode == 2 and "unknown argument" in p.stderr
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    p = subprocess.run([exe, "--preset", "CORNELL", "--width", "16", "--height", "16", "--out", str(tmp_path / "f")],
+                       capture_output=True, text=True)
+    assert p.returncode == 1 and "error:" in p.stderr and not os.path.exists(tmp_path / "f.pfm")
+
+
 # ---- compressed 8-wide tree (bvh.h "BVH8Q"): what the default traversal kernel walks ----------------------------------
 def _decode8(n8):
     """Fields of the [n, 20] uint32 node array."""
