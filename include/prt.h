@@ -88,6 +88,23 @@ typedef struct PrtMesh {
     uint32_t material_id;
 } PrtMesh;
 
+/* One placed copy of a mesh.  Semantically a run of Triangle primitives that share one Transform:
+ * struct Primitive {Shape = Triangle, Material, Transform{Mat, Inv}} (src/core/primitive.h:7-12), intersected exactly as
+ * PrimitiveList::Intersect does it (src/core/primitive.cpp:29-43): local origin = Inv * o, local direction =
+ * normalize(transpose(mat3(Mat)) * d), Triangle::Intersect in the mesh's own space, position back through Mat, normal
+ * through Inv, distance measured in world space.  The transform must be rotation + uniform scale + translation
+ * (prt_set_scene rejects anything else): only then is the reference's direction transform a ray transform, so that
+ * an acceleration structure in the mesh's space returns what the reference's linear scan returns.
+ * `mesh` indexes PrtSceneDesc.instanced_meshes (their own material_id is ignored). */
+typedef struct PrtInstance {
+    uint32_t mesh;
+    uint32_t material_id;
+    float mat[16];
+    float inv[16];
+} PrtInstance;
+
+/* Primitive order (= tie-break order of the closest hit): analytic primitives, then the triangles of `meshes` in mesh
+ * and face order, then the triangles of `instances` in instance and face order. */
 typedef struct PrtSceneDesc {
     const PrtMaterial* materials;
     const PrtPrimitive* primitives;
@@ -96,6 +113,10 @@ typedef struct PrtSceneDesc {
     uint32_t n_primitives;
     uint32_t n_meshes;
     float sky[3]; /* reference literal (0.4,0.3,0.6): src/backend/cpu/renderer.h:31 */
+    const PrtMesh* instanced_meshes; /* meshes that only exist through `instances` (may be NULL) */
+    const PrtInstance* instances;
+    uint32_t n_instanced_meshes;
+    uint32_t n_instances;
 } PrtSceneDesc;
 
 /* Pinhole camera; right/up are derived exactly as Camera::Camera does (src/core/camera.h:10-16);

@@ -193,6 +193,19 @@ struct BNode {
 };
 }  // namespace
 
+struct OrcMesh {  // one instanced mesh in its own space, with the oracle's own BVH over it
+    std::vector<Tri> tris;
+    std::vector<BNode> nodes;
+    std::vector<uint32_t> order;
+    float pad = 0.0f;
+};
+struct OrcInstance {  // PrtInstance + the global index of its first triangle primitive
+    uint32_t mesh, material;
+    float mat[16], inv[16];
+    uint32_t prim_base;
+    float scale;  // uniform scale of mat (BVH culling only)
+};
+
 struct OrcScene {
     std::vector<PrtMaterial> materials;
     std::vector<PrtPrimitive> prims;
@@ -202,6 +215,9 @@ struct OrcScene {
     std::vector<BNode> nodes;
     std::vector<uint32_t> order;
     float pad = 0.0f;
+    // placed mesh copies (PrtInstance): global prim index = instances[i].prim_base + face
+    std::vector<OrcMesh> imeshes;
+    std::vector<OrcInstance> instances;
 };
 
 namespace {
@@ -259,7 +275,8 @@ inline void test_triangle(const OrcScene* s, uint32_t ti, V3 o, V3 d, Best* best
 }
 
 // ---- oracle BVH (median split; conservative culling) --------------------------------------------
-void build_bvh(OrcScene* s) {
+template <class S>
+void build_bvh(S* s, const std::vector<PrtPrimitive>& prims) {
     const uint32_t n = (uint32_t)s->tris.size();
     s->nodes.clear();
     s->order.resize(n);
@@ -276,7 +293,7 @@ void build_bvh(OrcScene* s) {
             scale = std::max(scale, std::max(fabsf(t.p[k].x), std::max(fabsf(t.p[k].y), fabsf(t.p[k].z))));
         }
     }
-    for (const PrtPrimitive& p : s->prims) {
+    for (const PrtPrimitive& p : prims) {
         for (int k = 12; k < 15; ++k) scale = std::max(scale, fabsf(p.mat[k]) + 1.0f);
     }
     // Conservative padding: generous (the oracle favours safety over speed).
@@ -363,23 +380,47 @@ inline float limit_from_d2(float d2, float pad) {
     return std::sqrt(d2) * 1.0001f + 4.0f * pad + 1e-6f;
 }
 
-void traverse_bvh(const OrcScene* s, V3 o, V3 d, Best* best) {
+// One placed triangle = one iteration of PrimitiveList::Intersect with the instance's Transform.
+inline void test_instance_triangle(const OrcScene* s, const OrcInstance& in, uint32_t face, V3 o, V3 d, Best* best) {
+    const Tri& t = s->imeshes[in.mesh].tris[face];
+    test_primitive(in.mat, in.inv, o, d, (int32_t)(in.prim_base + face), in.material, best,
+                   [&t](V3 lo, V3 ld, SI* si) {
+                       triangle_intersect(t.p[0], t.p[1], t.p[2], t.n[0], t.n[1], t.n[2], lo, ld, si);
+                   });
+}
+
+// Walks the BVH of world-space triangles (in == nullptr) or of one instance's mesh in the mesh's own space.
+// (o, d) is always the WORLD ray: the leaf tests transform it themselves, exactly as the reference does per primitive.
+template <class S>
+void traverse_bvh_of(const OrcScene* scene, const S* s, const OrcInstance* in, V3 o, V3 d, Best* best) {
     if (s->nodes.empty()) return;
-    // The triangles' local ray (identity Transform): origin unchanged, direction re-normalised
-    // (primitive.cpp:29-30).  Culling uses that local ray; results never depend on it.
-    V3 ld = transform_normal(kIdentity, d);
+    // The triangles' local ray (primitive.cpp:29-30): identity Transform: origin unchanged, direction re-normalised.
+    // Culling uses that local ray; results never depend on it.
+    const V3 lo = in ? transform_point(in->inv, o) : o;
+    V3 ld = transform_normal(in ? in->mat : kIdentity, d);
     V3 inv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
     int32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
-    float tlimit = limit_from_d2(best->d2, s->pad);
+    // world distance = scale * local ray parameter (rotation + uniform scale): a generous local bound
+    auto limit = [&]() {
+        const float w = limit_from_d2(best->d2, scene->pad);
+        if (!in || !(w < FLT_MAX)) return w;
+        return w / in->scale * 1.001f + 4.0f * s->pad + 1e-6f;
+    };
+    float tlimit = limit();
     while (sp > 0) {
         const BNode& nd = s->nodes[stack[--sp]];
-        float te = box_entry(nd, o, inv, tlimit);
+        float te = box_entry(nd, lo, inv, tlimit);
         if (te == INFINITY) continue;
         if (nd.left < 0) {
-            for (uint32_t k = nd.first; k < nd.first + nd.count; ++k) test_triangle(s, s->order[k], o, d, best);
-            tlimit = limit_from_d2(best->d2, s->pad);
+            for (uint32_t k = nd.first; k < nd.first + nd.count; ++k) {
+                if (in)
+                    test_instance_triangle(scene, *in, s->order[k], o, d, best);
+                else
+                    test_triangle(scene, s->order[k], o, d, best);
+            }
+            tlimit = limit();
         } else {
             if (sp + 2 > 128) {  // cannot happen for median split of < 2^60 triangles
                 sp = 0;
@@ -394,9 +435,12 @@ void traverse_bvh(const OrcScene* s, V3 o, V3 d, Best* best) {
 void closest_hit(const OrcScene* s, V3 o, V3 d, int use_bvh, Best* best) {
     for (uint32_t i = 0; i < s->prims.size(); ++i) test_analytic(s, i, o, d, best);
     if (use_bvh) {
-        traverse_bvh(s, o, d, best);
+        traverse_bvh_of(s, s, (const OrcInstance*)nullptr, o, d, best);
+        for (const OrcInstance& in : s->instances) traverse_bvh_of(s, &s->imeshes[in.mesh], &in, o, d, best);
     } else {
         for (uint32_t i = 0; i < s->tris.size(); ++i) test_triangle(s, i, o, d, best);
+        for (const OrcInstance& in : s->instances)
+            for (uint32_t f = 0; f < s->imeshes[in.mesh].tris.size(); ++f) test_instance_triangle(s, in, f, o, d, best);
     }
     if (!(best->d2 < FLT_MAX)) {  // primitive.cpp:51-58
         best->prim = -1;
@@ -936,11 +980,46 @@ OrcScene* orc_scene_create(const PrtSceneDesc* desc) {
             s->tris.push_back(tri);
         }
     }
-    build_bvh(s);
+    build_bvh(s, s->prims);
+    uint32_t prim_base = (uint32_t)(s->prims.size() + s->tris.size());
+    s->imeshes.resize(desc->n_instanced_meshes);
+    for (uint32_t mi = 0; mi < desc->n_instanced_meshes; ++mi) {
+        const PrtMesh& m = desc->instanced_meshes[mi];
+        OrcMesh& om = s->imeshes[mi];
+        for (uint32_t t = 0; t < m.n_triangles; ++t) {
+            Tri tri;
+            for (int k = 0; k < 3; ++k) {
+                uint32_t vi = m.indices[3 * t + k];
+                tri.p[k] = ld3(m.positions + 3 * (size_t)vi);
+                tri.n[k] = ld3(m.normals + 3 * (size_t)vi);
+            }
+            tri.material = 0;
+            om.tris.push_back(tri);
+        }
+        build_bvh(&om, std::vector<PrtPrimitive>());
+    }
+    for (uint32_t i = 0; i < desc->n_instances; ++i) {
+        const PrtInstance& pi = desc->instances[i];
+        OrcInstance in;
+        in.mesh = pi.mesh;
+        in.material = pi.material_id;
+        memcpy(in.mat, pi.mat, sizeof(in.mat));
+        memcpy(in.inv, pi.inv, sizeof(in.inv));
+        in.prim_base = prim_base;
+        in.scale = std::sqrt(pi.mat[0] * pi.mat[0] + pi.mat[1] * pi.mat[1] + pi.mat[2] * pi.mat[2]);
+        prim_base += (uint32_t)s->imeshes[pi.mesh].tris.size();
+        s->instances.push_back(in);
+        // the world-space culling pad must cover the placed copies as well
+        for (int k = 12; k < 15; ++k) s->pad = std::max(s->pad, (fabsf(pi.mat[k]) + 1.0f) * 1e-4f);
+    }
     return s;
 }
 void orc_scene_destroy(OrcScene* s) { delete s; }
-uint32_t orc_scene_prim_count(const OrcScene* s) { return (uint32_t)(s->prims.size() + s->tris.size()); }
+uint32_t orc_scene_prim_count(const OrcScene* s) {
+    uint32_t n = (uint32_t)(s->prims.size() + s->tris.size());
+    for (const OrcInstance& in : s->instances) n += (uint32_t)s->imeshes[in.mesh].tris.size();
+    return n;
+}
 
 void orc_closest_hit(const OrcScene* s, uint32_t n, const float* origins, const float* dirs, PrtHit* hits,
                      int use_bvh, int n_threads) {

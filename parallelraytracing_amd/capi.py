@@ -40,10 +40,16 @@ class PrtMesh(C.Structure):
                 ("material_id", C.c_uint32)]
 
 
+class PrtInstance(C.Structure):
+    _fields_ = [("mesh", C.c_uint32), ("material_id", C.c_uint32), ("mat", C.c_float * 16), ("inv", C.c_float * 16)]
+
+
 class PrtSceneDesc(C.Structure):
     _fields_ = [("materials", C.POINTER(PrtMaterial)), ("primitives", C.POINTER(PrtPrimitive)),
                 ("meshes", C.POINTER(PrtMesh)), ("n_materials", C.c_uint32), ("n_primitives", C.c_uint32),
-                ("n_meshes", C.c_uint32), ("sky", C.c_float * 3)]
+                ("n_meshes", C.c_uint32), ("sky", C.c_float * 3),
+                ("instanced_meshes", C.POINTER(PrtMesh)), ("instances", C.POINTER(PrtInstance)),
+                ("n_instanced_meshes", C.c_uint32), ("n_instances", C.c_uint32)]
 
 
 class PrtCameraDesc(C.Structure):

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -47,6 +48,9 @@ struct PrtContext {
     BvhBuild bvh;
     std::vector<float> tri_records;   // 12 floats per triangle, leaf order
     std::vector<float> nrm_records;   // 12 floats per triangle, leaf order
+    std::vector<uint32_t> nodes8_all;  // scenes with placed mesh copies: top-level tree + every mesh's tree
+    std::vector<DevInstance> dev_insts;
+    std::vector<uint32_t> tlas_inst;   // top-level leaf slot -> instance
     PrtBvhInfo bvh_info{};
     DevScene dsc{};
     void* d_prims = nullptr;
@@ -55,6 +59,8 @@ struct PrtContext {
     void* d_nodes = nullptr;
     void* d_nodes4 = nullptr;
     void* d_nodes8 = nullptr;
+    void* d_insts = nullptr;
+    void* d_tlas_inst = nullptr;
     void* d_tris = nullptr;
     void* d_nrms = nullptr;
 
@@ -208,6 +214,8 @@ void free_scene(PrtContext* c) {
     free_dev(c->d_nodes);
     free_dev(c->d_nodes4);
     free_dev(c->d_nodes8);
+    free_dev(c->d_insts);
+    free_dev(c->d_tlas_inst);
     free_dev(c->d_tris);
     free_dev(c->d_nrms);
     c->has_scene = false;
@@ -292,7 +300,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         const uint32_t* front_count = c->d_counts + (size_t)d * PRT_CNT_STRIDE;
         if (c->dsc.n_nodes) {  // only the front part of the buffer can hit a triangle
             if ((rc = begin_event(c, 1, &ep))) return rc;
-            if (c->variant == 0)
+            if (c->variant == 0 || c->dsc.n_insts)  // placed mesh copies: only the two-level 8-wide kernel
                 prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
                                     c->bvh.max_stack4, c->tune, trav_stats);
             else
@@ -386,7 +394,8 @@ int prt_set_stream(PrtContext* c, void* hip_stream) {
 
 int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     if (!c || !s) return PRT_ERR_INVALID;
-    if ((s->n_materials && !s->materials) || (s->n_primitives && !s->primitives) || (s->n_meshes && !s->meshes))
+    if ((s->n_materials && !s->materials) || (s->n_primitives && !s->primitives) || (s->n_meshes && !s->meshes) ||
+        (s->n_instanced_meshes && !s->instanced_meshes) || (s->n_instances && !s->instances))
         return fail(c, PRT_ERR_INVALID, "null array in scene description");
     // ---- validate + flatten (host) ----
     c->materials.assign(s->materials, s->materials + s->n_materials);
@@ -486,6 +495,208 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         d.root_min[t % 3] = std::min(d.root_min[t % 3], verts[t]);
         d.root_max[t % 3] = std::max(d.root_max[t % 3], verts[t]);
     }
+    // ---- placed mesh copies (PrtInstance): one tree per instanced mesh in its own space + a top-level tree over the
+    // copies' world boxes; the world-space meshes above become one identity instance ----
+    c->nodes8_all.clear();
+    c->dev_insts.clear();
+    c->tlas_inst.clear();
+    if (s->n_instances) {
+        const uint32_t n_world = (uint32_t)n_tris;
+        if (n_world && c->bvh.nodes8.empty()) return fail(c, PRT_ERR_INVALID, "instances need the 8-wide tree (leaves <= 3 triangles)");
+        struct Blas {
+            BvhBuild bvh;
+            uint32_t slot_base = 0, node_base = 0, n_tris = 0;
+            float mn[3], mx[3], extent = 0.0f;
+        };
+        std::vector<Blas> blas(s->n_instanced_meshes);
+        uint64_t slots = n_world;
+        for (uint32_t m = 0; m < s->n_instanced_meshes; ++m) {
+            const PrtMesh& me = s->instanced_meshes[m];
+            if (!me.n_triangles || !me.positions || !me.normals || !me.indices)
+                return fail(c, PRT_ERR_INVALID, "instanced mesh %u: positions, normals and indices are required", m);
+            Blas& B = blas[m];
+            B.n_tris = me.n_triangles;
+            std::vector<float> v(9 * (size_t)me.n_triangles), nn(9 * (size_t)me.n_triangles);
+            for (int a = 0; a < 3; ++a) {
+                B.mn[a] = FLT_MAX;
+                B.mx[a] = -FLT_MAX;
+            }
+            for (uint32_t k = 0; k < me.n_triangles; ++k)
+                for (int vv = 0; vv < 3; ++vv) {
+                    const uint32_t vi = me.indices[3 * (size_t)k + vv];
+                    if (vi >= me.n_vertices) return fail(c, PRT_ERR_INVALID, "instanced mesh %u: vertex index out of range", m);
+                    for (int a = 0; a < 3; ++a) {
+                        const float pv = me.positions[3 * (size_t)vi + a];
+                        if (!std::isfinite(pv)) return fail(c, PRT_ERR_INVALID, "instanced mesh %u: non-finite vertex", m);
+                        v[9 * (size_t)k + 3 * vv + a] = pv;
+                        nn[9 * (size_t)k + 3 * vv + a] = me.normals[3 * (size_t)vi + a];
+                        B.mn[a] = std::min(B.mn[a], pv);
+                        B.mx[a] = std::max(B.mx[a], pv);
+                        B.extent = std::max(B.extent, std::fabs(pv));
+                    }
+                }
+            if (!bvh_build(v.data(), me.n_triangles, kMaxLeaf, 0, kMaxStack, &B.bvh) || B.bvh.nodes8.empty())
+                return fail(c, PRT_ERR_INVALID, "instanced mesh %u: BVH construction failed", m);
+            B.slot_base = (uint32_t)slots;
+            slots += me.n_triangles;
+            if (slots >= (1ull << 26)) return fail(c, PRT_ERR_INVALID, "too many triangles (limit 2^26 - 1)");
+            // triangle / normal records in this mesh's leaf order: {P0, face index}, {P1, -}, {P2, -}
+            c->tri_records.resize(12 * (size_t)slots, 0.0f);
+            c->nrm_records.resize(12 * (size_t)slots, 0.0f);
+            for (uint32_t sl = 0; sl < me.n_triangles; ++sl) {
+                const uint32_t t = B.bvh.order[sl];
+                float* r = &c->tri_records[12 * ((size_t)B.slot_base + sl)];
+                float* q = &c->nrm_records[12 * ((size_t)B.slot_base + sl)];
+                for (int vv = 0; vv < 3; ++vv)
+                    for (int a = 0; a < 3; ++a) {
+                        r[4 * vv + a] = v[9 * (size_t)t + 3 * vv + a];
+                        q[4 * vv + a] = nn[9 * (size_t)t + 3 * vv + a];
+                    }
+                memcpy(&r[3], &t, 4);
+            }
+        }
+        // the instance table: [identity instance of the world-space meshes] + the placed copies
+        auto identity12 = [](float* m12) {
+            for (int k = 0; k < 12; ++k) m12[k] = 0.0f;
+            m12[0] = m12[4] = m12[8] = 1.0f;
+        };
+        std::vector<std::array<float, 6>> boxes;
+        if (n_world) {
+            DevInstance I{};
+            identity12(I.mat);
+            identity12(I.inv);
+            I.root = 0;  // fixed up below
+            I.slot_base = 0;
+            I.prim_base = 0;  // the world triangles' records carry their full primitive index
+            I.virt_base = 0;
+            I.material = 0xFFFFFFFFu;  // per triangle record
+            I.n_tris = n_world;
+            I.inv_scale = 1.0f;
+            I.extent = extent;
+            c->dev_insts.push_back(I);
+            boxes.push_back({d.root_min[0], d.root_min[1], d.root_min[2], d.root_max[0], d.root_max[1], d.root_max[2]});
+        }
+        uint32_t virt = n_world, prim = n_prims + n_world;
+        for (uint32_t i = 0; i < s->n_instances; ++i) {
+            const PrtInstance& pi = s->instances[i];
+            if (pi.mesh >= s->n_instanced_meshes) return fail(c, PRT_ERR_INVALID, "instance %u: mesh out of range", i);
+            if (pi.material_id >= s->n_materials) return fail(c, PRT_ERR_INVALID, "instance %u: material out of range", i);
+            // rotation + uniform scale + translation only: transpose(M3) * M3 = s^2 * I, and inv * mat = I
+            const float* M = pi.mat;
+            double g[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    g[a][b] = (double)M[4 * a] * M[4 * b] + (double)M[4 * a + 1] * M[4 * b + 1] + (double)M[4 * a + 2] * M[4 * b + 2];
+            const double s2 = g[0][0];
+            bool ok = s2 > 1e-20 && std::isfinite(s2);
+            for (int a = 0; a < 3 && ok; ++a)
+                for (int b = 0; b < 3; ++b)
+                    if (std::fabs(g[a][b] - (a == b ? s2 : 0.0)) > 1e-4 * s2) ok = false;
+            for (int r = 0; r < 4 && ok; ++r)
+                for (int cc = 0; cc < 4; ++cc) {
+                    double acc = 0.0;
+                    for (int kk = 0; kk < 4; ++kk) acc += (double)pi.inv[4 * kk + r] * (double)pi.mat[4 * cc + kk];
+                    if (std::fabs(acc - (r == cc ? 1.0 : 0.0)) > 1e-3) ok = false;
+                }
+            if (!ok || M[3] != 0.0f || M[7] != 0.0f || M[11] != 0.0f || M[15] != 1.0f)
+                return fail(c, PRT_ERR_INVALID,
+                            "instance %u: the transform must be rotation + uniform scale + translation with inv = inverse(mat) "
+                            "(the reference's local ray, primitive.cpp:29-30, is only a ray transform for those)", i);
+            const Blas& B = blas[pi.mesh];
+            DevInstance I{};
+            to_dev_mat(pi.mat, I.mat);
+            to_dev_mat(pi.inv, I.inv);
+            I.slot_base = B.slot_base;
+            I.prim_base = prim;
+            I.virt_base = virt;
+            I.material = pi.material_id;
+            I.n_tris = B.n_tris;
+            I.inv_scale = (float)(1.0 / std::sqrt(s2));
+            I.extent = B.extent;
+            I.root = pi.mesh;  // mesh index for now; node base below
+            c->dev_insts.push_back(I);
+            virt += B.n_tris;
+            prim += B.n_tris;
+            // world box: the 8 corners of the mesh box through Mat, widened by a relative slack for the fp32 rounding
+            // of Mat * p anywhere inside the box
+            std::array<float, 6> bx{FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+            float mag = 0.0f;
+            for (int corner = 0; corner < 8; ++corner) {
+                const float p3[3] = {(corner & 1) ? B.mx[0] : B.mn[0], (corner & 2) ? B.mx[1] : B.mn[1], (corner & 4) ? B.mx[2] : B.mn[2]};
+                for (int a = 0; a < 3; ++a) {
+                    const float wv = (M[a] * p3[0] + M[4 + a] * p3[1]) + (M[8 + a] * p3[2] + M[12 + a]);
+                    bx[a] = std::min(bx[a], wv);
+                    bx[3 + a] = std::max(bx[3 + a], wv);
+                    mag = std::max(mag, std::fabs(wv));
+                }
+            }
+            for (int a = 0; a < 3; ++a) {
+                bx[a] -= 1e-5f * (mag + 1e-30f);
+                bx[3 + a] += 1e-5f * (mag + 1e-30f);
+            }
+            boxes.push_back(bx);
+        }
+        if ((uint64_t)virt + n_prims >= 0xFFFFFFF0ull) return fail(c, PRT_ERR_INVALID, "too many placed triangles");
+        // top-level tree: the same builder over one degenerate "triangle" per instance that spans its world box
+        const uint32_t n_inst_total = (uint32_t)c->dev_insts.size();
+        std::vector<float> pv(9 * (size_t)n_inst_total);
+        for (uint32_t i = 0; i < n_inst_total; ++i) {
+            const std::array<float, 6>& bx = boxes[i];
+            const float tri[9] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[0], bx[4], bx[2]};
+            memcpy(&pv[9 * (size_t)i], tri, sizeof(tri));
+        }
+        BvhBuild top;
+        if (!bvh_build(pv.data(), n_inst_total, kMaxLeaf, 1, kMaxStack, &top) || top.nodes8.empty())
+            return fail(c, PRT_ERR_INVALID, "top-level BVH construction failed");
+        c->tlas_inst = top.order;
+        // one node array: [top level][world meshes' tree][instanced meshes' trees]; child_base / tri_base made absolute
+        c->nodes8_all = top.nodes8;
+        uint32_t max_blas_depth = 0;
+        auto append = [&](const std::vector<uint32_t>& n8, uint32_t slot_base) -> uint32_t {
+            const uint32_t node_base = (uint32_t)(c->nodes8_all.size() / 20);
+            const size_t at = c->nodes8_all.size();
+            c->nodes8_all.insert(c->nodes8_all.end(), n8.begin(), n8.end());
+            for (size_t k = at; k < c->nodes8_all.size(); k += 20) {
+                c->nodes8_all[k + 4] += node_base;
+                c->nodes8_all[k + 5] += slot_base;
+            }
+            return node_base;
+        };
+        uint32_t world_root = 0;
+        if (n_world) {
+            world_root = append(c->bvh.nodes8, 0);
+            max_blas_depth = c->bvh.depth8;
+        }
+        for (Blas& B : blas) {
+            B.node_base = append(B.bvh.nodes8, B.slot_base);
+            max_blas_depth = std::max(max_blas_depth, B.bvh.depth8);
+        }
+        for (size_t i = 0; i < c->dev_insts.size(); ++i) {
+            DevInstance& I = c->dev_insts[i];
+            I.root = (n_world && i == 0) ? world_root : blas[I.root].node_base;
+        }
+        if (top.depth8 + max_blas_depth > 15u)
+            return fail(c, PRT_ERR_INVALID, "two-level BVH too deep for the traversal stack (%u + %u > 15)", top.depth8, max_blas_depth);
+        // scene-wide quantities the producers use
+        for (int a = 0; a < 3; ++a) {
+            d.root_min[a] = FLT_MAX;
+            d.root_max[a] = -FLT_MAX;
+        }
+        for (const std::array<float, 6>& bx : boxes)
+            for (int a = 0; a < 3; ++a) {
+                d.root_min[a] = std::min(d.root_min[a], bx[a]);
+                d.root_max[a] = std::max(d.root_max[a], bx[3 + a]);
+                extent = std::max(extent, std::max(std::fabs(bx[a]), std::fabs(bx[3 + a])));
+            }
+        d.extent = extent;
+        d.n_insts = n_inst_total;
+        d.n_nodes = std::max(d.n_nodes, 1u);  // "the scene has a BVH"
+        d.n_tris = (uint32_t)slots;
+        bi.n_nodes8 = (uint32_t)(c->nodes8_all.size() / 20);
+        bi.depth8 = top.depth8 + max_blas_depth;
+        bi.n_triangles = (uint32_t)slots;
+        bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
+    }
     c->has_scene = true;
     if (!c->has_device) return PRT_OK;  // host-only context: BVH built, nothing to upload
 
@@ -514,7 +725,12 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
     HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
     HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
-    if (!c->bvh.nodes8.empty()) HIPCHECK(c, upload(&c->d_nodes8, c->bvh.nodes8.data(), c->bvh.nodes8.size() * 4));
+    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
+    if (!n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
+    if (!c->dev_insts.empty()) {
+        HIPCHECK(c, upload(&c->d_insts, c->dev_insts.data(), c->dev_insts.size() * sizeof(DevInstance)));
+        HIPCHECK(c, upload(&c->d_tlas_inst, c->tlas_inst.data(), c->tlas_inst.size() * 4));
+    }
     HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
     HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
     d.prims = (const DevPrim*)c->d_prims;
@@ -522,6 +738,8 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.mat_type = (const uint32_t*)c->d_mat_type;
     d.nodes = (const float4*)c->d_nodes;
     d.nodes4 = (const float4*)c->d_nodes4;
+    d.insts = (const DevInstance*)c->d_insts;
+    d.tlas_inst = (const uint32_t*)c->d_tlas_inst;
     d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
     d.tris = (const float4*)c->d_tris;
     d.tri_normals = (const float4*)c->d_nrms;
@@ -765,7 +983,7 @@ int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float
     if ((rc = ensure_spill(c))) return rc;
     prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], cnt, c->d_work, n, nullptr);
     if (c->dsc.n_nodes) {
-        if (c->variant == 0)
+        if (c->variant == 0 || c->dsc.n_insts)
             prt_launch_traverse(c->stream, c->dsc, c->rb[0], cnt, c->d_work, c->d_spill, n, c->bvh.max_depth,
                                 c->bvh.max_stack4, c->tune, nullptr);
         else
@@ -916,7 +1134,8 @@ int prt_bvh_read4(PrtContext* c, float* nodes4) {
 int prt_bvh_read8(PrtContext* c, uint32_t* nodes8) {
     if (!c) return PRT_ERR_INVALID;
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
-    if (nodes8) memcpy(nodes8, c->bvh.nodes8.data(), c->bvh.nodes8.size() * 4);
+    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
+    if (nodes8) memcpy(nodes8, n8.data(), n8.size() * 4);
     return PRT_OK;
 }
 

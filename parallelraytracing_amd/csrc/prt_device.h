@@ -207,10 +207,49 @@ PRT_DEV void triangle_world_hit(const DevScene& sc, uint32_t slot, f3 o, f3 d, W
     w.d2 = dist2(o, pos);
 }
 
+// A triangle of a placed mesh copy: the loop body of PrimitiveList::Intersect with the copy's Transform
+// (src/core/primitive.cpp:29-43): local ray, Triangle::Intersect in the mesh's space, position back through Mat, normal
+// through Inv, distance in world space.  v = hit id - n_prims.
+PRT_DEV void instance_world_hit(const DevScene& sc, uint32_t v, f3 o, f3 d, WorldHit& w) {
+    uint32_t lo = 0, hi = sc.n_insts;  // the copy whose [virt_base, virt_base + n_tris) holds v
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sc.insts[mid].virt_base <= v) lo = mid; else hi = mid;
+    }
+    const DevInstance& I = sc.insts[lo];
+    const uint32_t slot = I.slot_base + (v - I.virt_base);
+    const float4 a = sc.tris[3 * (size_t)slot + 0];
+    const float4 b = sc.tris[3 * (size_t)slot + 1];
+    const float4 c = sc.tris[3 * (size_t)slot + 2];
+    const f3 lo_ = transform_point(I.inv, o);
+    const f3 ld = transform_normal(I.mat, d);
+    f3 pos;
+    float b1, b2;
+    w.has = triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), lo_, ld, pos, b1, b2);
+    if (!w.has) return;
+    const float4 n0 = sc.tri_normals[3 * (size_t)slot + 0];
+    const float4 n1 = sc.tri_normals[3 * (size_t)slot + 1];
+    const float4 n2 = sc.tri_normals[3 * (size_t)slot + 2];
+    f3 n = (1.0f - b1 - b2) * mk3(n0.x, n0.y, n0.z) + b1 * mk3(n1.x, n1.y, n1.z) + b2 * mk3(n2.x, n2.y, n2.z);
+    w.front = true;
+    if (dot3(n, ld) > 0.0f) {
+        n = n * -1.0f;
+        w.front = false;
+    }
+    w.pos = transform_point(I.mat, pos);
+    w.normal = transform_normal(I.inv, n);
+    w.material = I.material == 0xFFFFFFFFu ? __float_as_uint(b.w) : I.material;  // world-space meshes: per triangle
+    w.prim = (int32_t)(I.prim_base + __float_as_uint(a.w));
+    w.d2 = dist2(o, w.pos);
+}
+
+template <bool INST = false>
 PRT_DEV void world_hit_from_id(const DevScene& sc, uint32_t id, f3 o, f3 d, WorldHit& w) {
     if (id < sc.n_prims) {
         analytic_hit(sc.prims[id], o, d, w);
         w.prim = (int32_t)id;
+    } else if (INST) {
+        instance_world_hit(sc, id - sc.n_prims, o, d, w);
     } else {
         triangle_world_hit(sc, id - sc.n_prims, o, d, w);
     }

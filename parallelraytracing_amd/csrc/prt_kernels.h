@@ -24,6 +24,19 @@ struct DevCamera {  // the Camera members GetCameraRay reads (reference: src/cor
     float W, H, tan_fov_y;
 };
 
+// One placed mesh copy (PrtInstance) as the kernels see it: 128 B.  mat / inv: rows 0..2 of the column-major mat4
+// (like DevPrim).  root: its mesh's root in nodes8; slot_base: first triangle slot of its mesh in tris / tri_normals;
+// prim_base: global primitive index of its first triangle (tie-break order); virt_base: first hit id of this copy
+// minus n_prims (hit id = n_prims + virt_base + slot - slot_base).
+struct DevInstance {
+    float mat[12];
+    float inv[12];
+    uint32_t root, slot_base, prim_base, virt_base;
+    uint32_t material, n_tris;
+    float inv_scale;  // 1 / uniform scale of mat
+    float extent;     // max |coordinate| of the mesh in its own space (culling pad)
+};
+
 struct DevScene {
     const DevPrim* prims;
     const float4* mat_rgbs;     // rgb + scalar
@@ -33,6 +46,9 @@ struct DevScene {
     const uint4* nodes8;        // 5 x uint4 per compressed 8-wide node (see bvh.h); null if the tree has none
     const float4* tris;         // 3 x float4 per triangle, leaf order: {P0, prim}, {P1, material}, {P2, 0}
     const float4* tri_normals;  // 3 x float4 per triangle, leaf order
+    const DevInstance* insts;   // placed mesh copies; with n_insts > 0 nodes8 starts with a top-level tree over them
+    const uint32_t* tlas_inst;  // top-level leaf slot -> instance index
+    uint32_t n_insts;
     uint32_t n_prims;
     uint32_t n_nodes;
     uint32_t n_tris;

@@ -130,7 +130,7 @@ PRT_DEV float4 path_result(f3 L, float clamp, uint32_t depth) {
     return make_float4(L.x, L.y, L.z, __uint_as_float(depth));
 }
 
-template <int BUDGET>
+template <int BUDGET, bool INST>
 PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr, uint32_t& rng, uint32_t& depth,
                          uint32_t max_depth, const PrtSampling& sp, float4* __restrict__ rad_slot, uint32_t& id0,
                          float& d2_0) {
@@ -151,7 +151,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             return 2;
         }
         WorldHit w;
-        world_hit_from_id(sc, id, o, d, w);
+        world_hit_from_id<INST>(sc, id, o, d, w);
         const uint32_t type = sc.mat_type[w.material];
         const float4 rgbs = sc.mat_rgbs[w.material];
         f3 atten, emitted, so, sd;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 front = classify_ray(sc, o, d, id0, d2_0);
             }
             if (!front) {
-                const int r = advance_path<0>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
+                const int r = advance_path<0, false>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
                 front = r == 1;
                 back = r == 2;
             }
@@ -1239,7 +1239,15 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // ---------------------------------------------------------------------------------------------------------
 #define T8_QCAP 256u  // work items of one wave between two triangle phases
 
-template <int STACK_L, int WAVES, bool STATS>
+// INST = true (scenes with placed mesh copies, PrtInstance): nodes8 starts with a TOP-LEVEL tree whose "triangles" are
+// instances.  A lane that finds instance hits there saves its top-level group, pushes a sentinel and restarts in the
+// instance's tree with the reference's per-primitive local ray (local origin = Inv * o, local direction =
+// normalize(transpose(mat3(Mat)) * d), primitive.cpp:29-30); popping the sentinel restores the world ray.  All
+// triangles live in instance space (world-space meshes form one identity instance, which reproduces the
+// non-instanced results bit for bit); a candidate's key is its WORLD distance^2 |o - Mat * pos|^2 and its global
+// primitive index, as in the reference.  A lane changes level only when none of its items is left in the queue.
+#define T8_SENTINEL 0xFFFFFFFFu
+template <int STACK_L, int WAVES, bool STATS, bool INST>
 __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
@@ -1275,6 +1283,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     uint32_t gx = 0u, gy = 0u;    // current node group
     uint32_t tBb = 0u, tBm = 0u;  // a triangle group that did not fit the queue (the lane waits for the next phase)
     bool pending = false;         // this lane has items in the wave's queue
+    // INST only: level (0 = top-level tree, world ray; 1 = inside an instance, local ray), the instance, the pending
+    // instance hits of the current top-level node, the culling-bound conversion (world distance -> local parameter)
+    bool in_blas = false, stall = false;
+    uint32_t inst = 0u, ipb = 0u, ipm = 0u;
+    float lscale = 1.0f, padw4 = 0.0f;
     int sp = 0;
     bool overflow = false;
     Closest best;
@@ -1294,13 +1307,17 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             break;
         }
         // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
-        if (k != 0xFFFFFFFFu && !pending && tBm == 0u) {
+        if (k != 0xFFFFFFFFu && !pending && tBm == 0u && !(INST && (in_blas || ipm != 0u))) {
             if (overflow) {
-                const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable 4-wide instance
-                if (j < PRT_OVF_CAP)
-                    ovf[1u + j] = k;
-                else
-                    atomicOr(work + 256, 2u);
+                if (INST) {
+                    atomicOr(work + 256, 2u);  // no fallback for two-level scenes: prt_synchronize reports it
+                } else {
+                    const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable 4-wide instance
+                    if (j < PRT_OVF_CAP)
+                        ovf[1u + j] = k;
+                    else
+                        atomicOr(work + 256, 2u);
+                }
                 overflow = false;
                 k = 0xFFFFFFFFu;
             } else if (!(gy > 0x00FFFFFFu) && sp == 0) {
@@ -1352,6 +1369,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         gx = 0u;  // the root "group": node 0, one pending hit that decodes to slot 0
                         gy = 1u << (24u + octinv);
                         sp = 0;
+                        if (INST) {
+                            in_blas = false;
+                            ipm = 0u;
+                            lscale = 1.0f;
+                            padw4 = 0.0f;
+                        }
                     }
                 }
                 cur = (cur + n_idle < cur_end) ? cur + n_idle : cur_end;
@@ -1363,12 +1386,74 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         }
         // ---- phase 1: node steps.  Triangles found go straight to the wave's queue and the lane keeps walking;
         // leave when at most exit_max lanes can still walk or enough work for a triangle phase has piled up ----
-        bool walk = (k != 0xFFFFFFFFu) && tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0);
+        bool walk = (k != 0xFFFFFFFFu) && tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u)) && !(INST && stall);
         while (walk) {
             // current group: G while it has pending internal hits, else the top of the stack (read unconditionally)
             const int spr = sp > 0 ? sp - 1 : 0;
             const uint2 top = s_stack[spr * 256 + tid];
             const bool has = gy > 0x00FFFFFFu;
+            if (INST) {
+                const bool enter = !in_blas && ipm != 0u;               // instance hits of the last top-level node first
+                const bool leave = !enter && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
+                if (enter || leave) {
+                    if (pending) {  // queued triangles still refer to the current ray: wait for the triangle phase
+                        stall = true;
+                    } else {
+                        const float4 O = ro[k];
+                        const float4 D = rd[k];
+                        f3 dw = mk3(D.x, D.y, D.z);
+                        o = mk3(O.x, O.y, O.z);
+                        const float pad_w = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                        if (enter) {
+                            inst = sc.tlas_inst[ipb + (uint32_t)__builtin_ctz(ipm)];
+                            ipm &= ipm - 1u;
+                            if (has) {  // the remaining top-level siblings wait below the sentinel
+                                s_stack[sp * 256 + tid] = make_uint2(gx, gy);
+                                ++sp;
+                            }
+                            s_stack[(sp <= STACK_L ? sp : STACK_L) * 256 + tid] = make_uint2(T8_SENTINEL, 0xFF000000u);
+                            ++sp;
+                            const DevInstance& I = sc.insts[inst];
+                            o = transform_point(I.inv, o);      // primitive.cpp:29
+                            ld = transform_normal(I.mat, dw);   // primitive.cpp:30
+                            pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + I.extent);
+                            lscale = I.inv_scale * 1.000001f;
+                            padw4 = 4.0f * pad_w;
+                            gx = I.root;
+                            in_blas = true;
+                        } else {
+                            sp = spr;  // pop the sentinel
+                            ld = normalize3(dw);
+                            pad = pad_w;
+                            lscale = 1.0f;
+                            padw4 = 0.0f;
+                            gx = 0u;
+                            in_blas = false;
+                        }
+                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+                        anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
+                        any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
+                        anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
+                        octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+                        octinv4 = octinv * 0x01010101u;
+                        tlimit = (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad;
+                        gy = enter ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
+                        if (sp > STACK_L) {  // no room left: give the ray up (an error the host reports)
+                            overflow = true;
+                            gy = 0u;
+                            sp = 0;
+                            ipm = 0u;
+                            in_blas = false;
+                        }
+                    }
+                    walk = tBm == 0u && !stall && ((gy > 0x00FFFFFFu) || sp > 0 || ipm != 0u);
+                    if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
+                    continue;
+                }
+            }
             const uint32_t cx = has ? gx : top.x;
             uint32_t cy = has ? gy : top.y;
             sp = has ? sp : spr;
@@ -1437,6 +1522,13 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 overflow = true;
                 gy = 0u;
                 sp = 0;
+                if (INST) {
+                    ipm = 0u;
+                    in_blas = false;
+                }
+            } else if (INST && !in_blas) {  // top-level node: its "triangles" are instances, entered one by one
+                ipb = w1.y;
+                ipm = tm;
             } else if (tm != 0u) {
                 const uint32_t cnt = (uint32_t)__popc(tm);
                 const uint32_t pos = atomicAdd(&s_qn[wv], cnt);
@@ -1450,8 +1542,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     tBm = tm;
                 }
             }
-            q_lanes += (uint32_t)__popcll(__ballot(tm != 0u));
-            walk = tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0);
+            q_lanes += (uint32_t)__popcll(__ballot(tm != 0u && !(INST && !in_blas)));
+            walk = tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u));
             if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
         }
         // ---- phase 2: the queued (ray, triangle) pairs, one pair per lane per round ----
@@ -1488,6 +1580,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     const uint32_t slot = item & 0x03FFFFFFu;
                     const f3 qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
                     const f3 qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                    uint32_t qinst = 0u, qk = 0u, win = slot;
+                    if (INST) {
+                        qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
+                        qk = (uint32_t)__shfl((int)k, (int)owner, 64);
+                    }
                     bool cand = false;
                     unsigned long long key = 0ull;
                     if (act) {
@@ -1498,8 +1595,19 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         f3 pos;
                         float b1, b2;
                         if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), qo, qd, pos, b1, b2)) {
-                            const float d2 = dist2(qo, pos);
-                            key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(a.w);
+                            float d2;
+                            uint32_t prim;
+                            if (INST) {  // position back through Mat, distance in world space (primitive.cpp:38-43)
+                                const DevInstance& I = sc.insts[qinst];
+                                const float4 OW = ro[qk];
+                                d2 = dist2(mk3(OW.x, OW.y, OW.z), transform_point(I.mat, pos));
+                                prim = I.prim_base + __float_as_uint(a.w);
+                                win = I.virt_base + (slot - I.slot_base);
+                            } else {
+                                d2 = dist2(qo, pos);
+                                prim = __float_as_uint(a.w);
+                            }
+                            key = ((unsigned long long)__float_as_uint(d2) << 32) | prim;
                             // NaN / inf d2 have bit patterns above FLT_MAX's: they can never win, as in the reference
                             cand = true;
                             atomicMin(&s_key[wbase + owner], key);
@@ -1507,7 +1615,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     }
                     if (STATS && lane == 0) ++s_iters[4 + wv];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = slot;
+                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = win;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
                 const unsigned long long won = ((volatile unsigned long long*)s_key)[tid];
@@ -1515,9 +1623,10 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     best.d2 = __uint_as_float((uint32_t)(won >> 32));
                     best.prim = (uint32_t)won;
                     best.id = sc.n_prims + ((volatile uint32_t*)s_slot)[tid];
-                    tlimit = limit_from_d2(best.d2, pad);
+                    tlimit = INST ? (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad : limit_from_d2(best.d2, pad);
                 }
                 pending = false;  // everything that was queued has been tested
+                stall = false;
                 q_lanes = 0u;
             }
         }
@@ -1538,7 +1647,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-template <int FUSE, bool SAMPLING>
+template <int FUSE, bool SAMPLING, bool INST>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
@@ -1571,7 +1680,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
         if (id != HIT_DEAD) {
             o = mk3(O.x, O.y, O.z);
             d = mk3(D.x, D.y, D.z);
-            const int r = advance_path<1 + FUSE>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
+            const int r = advance_path<1 + FUSE, INST>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
             front = r == 1;
             back = r == 2;
         }
@@ -1715,7 +1824,10 @@ __global__ void k_hit_records(DevScene sc, uint32_t n, const float4* __restrict_
     if (id != HIT_MISS && id != HIT_DEAD) {
         const float4 O = ro[i], D = rd[i];
         WorldHit w;
-        world_hit_from_id(sc, id, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), w);
+        if (sc.n_insts)
+            world_hit_from_id<true>(sc, id, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), w);
+        else
+            world_hit_from_id<false>(sc, id, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), w);
         if (w.has) {
             h.prim = w.prim;
             h.front_face = w.front ? 1u : 0u;
@@ -1814,22 +1926,26 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((KERNEL<L, W, MODE, false>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,    \
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
-    if (tune.wide == 2u && sc.nodes8) {
+    if ((tune.wide == 2u || sc.n_insts) && sc.nodes8) {
         // default: compressed 8-wide tree; a ray needs at most depth8 - 1 stacked node groups.  15 entries at
         // 4 waves/SIMD or 11 entries at 5 waves/SIMD (tune.stack_lds == 5); deeper rays take the overflow list.
-#define PRT_LAUNCH_8(L, W)                                                                                         \
+#define PRT_LAUNCH_8(L, W, IN)                                                                                     \
     do {                                                                                                           \
         if (stats)                                                                                                 \
-            hipLaunchKernelGGL((k_traverse8_persistent<L, W, true>), grid, block, 0, st, sc, in.o, in.d, in.hit,   \
-                               in.hd2, count_ptr, work, ovf, tune, stats);                                         \
+            hipLaunchKernelGGL((k_traverse8_persistent<L, W, true, IN>), grid, block, 0, st, sc, in.o, in.d,       \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats);                                 \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_traverse8_persistent<L, W, false>), grid, block, 0, st, sc, in.o, in.d, in.hit,  \
-                               in.hd2, count_ptr, work, ovf, tune, stats);                                         \
+            hipLaunchKernelGGL((k_traverse8_persistent<L, W, false, IN>), grid, block, 0, st, sc, in.o, in.d,      \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats);                                 \
     } while (0)
+        if (sc.n_insts) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths)
+            PRT_LAUNCH_8(15, 4, true);
+            return;
+        }
         if (tune.stack_lds == 5u)
-            PRT_LAUNCH_8(11, 5);
+            PRT_LAUNCH_8(11, 5, false);
         else
-            PRT_LAUNCH_8(15, 4);
+            PRT_LAUNCH_8(15, 4, false);
 #undef PRT_LAUNCH_8
         hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
         PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
@@ -1889,14 +2005,16 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
                       uint32_t fuse_max, const PrtSampling& sp) {
     const dim3 grid((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK));
-#define PRT_SHADE(F, SA)                                                                                            \
-    hipLaunchKernelGGL((k_shade<F, SA>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, out.d,  \
-                       out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
+#define PRT_SHADE(F, SA, IN)                                                                                        \
+    hipLaunchKernelGGL((k_shade<F, SA, IN>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o,     \
+                       out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
     const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
-    if (fuse_max) {
-        if (sa) PRT_SHADE(1, true); else PRT_SHADE(1, false);
+    if (sc.n_insts) {  // scenes with placed mesh copies: one general instance
+        PRT_SHADE(0, true, true);
+    } else if (fuse_max) {
+        if (sa) PRT_SHADE(1, true, false); else PRT_SHADE(1, false, false);
     } else {
-        if (sa) PRT_SHADE(0, true); else PRT_SHADE(0, false);
+        if (sa) PRT_SHADE(0, true, false); else PRT_SHADE(0, false, false);
     }
 #undef PRT_SHADE
 }

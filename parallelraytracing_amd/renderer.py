@@ -17,8 +17,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import capi
-from .capi import (PrtBvhInfo, PrtCameraDesc, PrtHit, PrtMaterial, PrtMesh, PrtPrimitive, PrtSampling, PrtSceneDesc,
-                   PrtStats)
+from .capi import (PrtBvhInfo, PrtCameraDesc, PrtHit, PrtInstance, PrtMaterial, PrtMesh, PrtPrimitive, PrtSampling,
+                   PrtSceneDesc, PrtStats)
 
 _fp = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)
@@ -126,6 +126,8 @@ class Scene:
         self.materials: List[PrtMaterial] = []
         self.primitives: List[PrtPrimitive] = []
         self.meshes: List[Tuple[Mesh, int]] = []
+        self.instanced_meshes: List[Mesh] = []
+        self.instances: List[PrtInstance] = []
         self.sky = tuple(float(x) for x in sky)
         self._keep = None
         if preset is not None:
@@ -182,9 +184,30 @@ class Scene:
         """World-space triangles (identity Transform); appended after all analytic primitives."""
         self.meshes.append((mesh, int(material)))
 
+    def AddInstance(self, mesh: Mesh, material: int, scale=1.0, euler_deg=(0, 0, 0), translation=(0, 0, 0)):
+        """A placed copy of `mesh`: Triangle primitives sharing one Transform (src/core/primitive.h:7-12), built by
+        Scene::MakeTransform (src/core/scene.cpp:9-17).  Uniform scale only (include/prt.h, PrtInstance)."""
+        for k, m in enumerate(self.instanced_meshes):
+            if m is mesh:
+                mi = k
+                break
+        else:
+            self.instanced_meshes.append(mesh)
+            mi = len(self.instanced_meshes) - 1
+        inst = PrtInstance()
+        inst.mesh = mi
+        inst.material_id = int(material)
+        sc = (scale, scale, scale) if np.isscalar(scale) else scale
+        mat, inv = make_transform(sc, euler_deg, translation)
+        inst.mat[:] = mat.tolist()
+        inst.inv[:] = inv.tolist()
+        self.instances.append(inst)
+        return len(self.instances) - 1
+
     @property
     def n_triangles(self) -> int:
-        return sum(m.n_triangles for m, _ in self.meshes)
+        return (sum(m.n_triangles for m, _ in self.meshes)
+                + sum(self.instanced_meshes[i.mesh].n_triangles for i in self.instances))
 
     def desc(self) -> PrtSceneDesc:
         mats = (PrtMaterial * max(1, len(self.materials)))(*self.materials)
@@ -206,7 +229,19 @@ class Scene:
         d.n_primitives = len(self.primitives)
         d.n_meshes = len(self.meshes)
         d.sky[:] = self.sky
-        self._keep = (mats, prims, meshes)
+        imeshes = (PrtMesh * max(1, len(self.instanced_meshes)))()
+        for i, m in enumerate(self.instanced_meshes):
+            imeshes[i].positions = L.prt_mesh_positions(m._h)
+            imeshes[i].normals = L.prt_mesh_normals(m._h)
+            imeshes[i].indices = L.prt_mesh_indices(m._h)
+            imeshes[i].n_vertices = m.n_vertices
+            imeshes[i].n_triangles = m.n_triangles
+        insts = (PrtInstance * max(1, len(self.instances)))(*self.instances)
+        d.instanced_meshes = imeshes
+        d.instances = insts
+        d.n_instanced_meshes = len(self.instanced_meshes)
+        d.n_instances = len(self.instances)
+        self._keep = (mats, prims, meshes, imeshes, insts)
         return d
 
 

@@ -306,6 +306,91 @@ def test_image_parity_with_sampling_upgrades(kind, jitter, rr_depth, clamp):
     assert np.array_equal(film.accum, acc0)
 
 
+# ---- placed mesh copies (PrtInstance): two-level traversal ----------------------------------------------------------------
+INST_PLACEMENTS = [(1.0, (0, 0, 0), (0, 2.6, 0)), (0.5, (0, 40, 0), (2.5, 0, 0)), (1.5, (30, 0, 0), (-3, 0.5, -1)),
+                   (0.8, (10, 70, 25), (0, 0.3, 3)), (2.0, (0, 180, 0), (4.0, 1.0, -4.0))]
+
+
+def _instanced_scene(mesh, with_world_mesh):
+    sc = prt.Scene(preset=None)
+    g = sc.AddLambertian((0.5, 0.5, 0.5))
+    b = sc.AddLambertian((0.8, 0.6, 0.4))
+    m = sc.AddMetal((0.9, 0.9, 0.9), 0.1)
+    e = sc.AddEmissive((6, 6, 6))
+    sc.AddQuad(30, 30, g, translation=(0, -1.2, 0))
+    sc.AddQuad(4, 4, e, euler_deg=(180, 0, 0), translation=(0, 7, 0))
+    if with_world_mesh:
+        sc.AddMesh(mesh, b)
+    for i, (scale, euler, tr) in enumerate(INST_PLACEMENTS):
+        sc.AddInstance(mesh, b if i % 2 == 0 else m, scale=scale, euler_deg=euler, translation=tr)
+    return sc
+
+
+@pytest.mark.parametrize("with_world_mesh", [False, True])
+def test_closest_hit_instances_vs_linear_scan_bit_exact(with_world_mesh):
+    """Every placed triangle is a reference Primitive{Triangle, Material, Transform}: the two-level walk must return
+    what PrimitiveList::Intersect's linear scan returns (oracle, brute force), bit for bit."""
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply")).refine(1200)
+    scene = _instanced_scene(mesh, with_world_mesh)
+    r, _, _ = make_renderer(scene, 16, 16)
+    info = r.bvh_info()
+    assert info.n_nodes8 > 0 and info.depth8 <= 15
+    rng = np.random.default_rng(21)
+    o, d = util.random_rays(rng, 6000, center=(0, 0.5, 0), radius=11.0, spread=4.5)
+    o2 = rng.uniform(-4, 4, size=(3000, 3)).astype(np.float32)
+    d2 = np.stack([prt.glm_normalize(v) for v in rng.normal(size=o2.shape).astype(np.float32)])
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    got = r.closest_hit(o, d)
+    want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
+    assert util.hits_equal(got, want) == []
+    nt = mesh.n_triangles
+    owners = set(((got["prim"][got["prim"] >= 2] - 2) // nt).tolist())
+    assert owners == set(range(len(INST_PLACEMENTS) + (1 if with_world_mesh else 0)))
+
+
+def test_identity_instance_renders_like_the_world_space_mesh():
+    mesh = prt.scenes.refined("bunny.ply", 20_000)
+    a = prt.scenes.mesh_scene(mesh)
+    b = prt.Scene(preset=None)
+    b.materials = list(a.materials)
+    b.primitives = list(a.primitives)
+    b.AddInstance(mesh, a.meshes[0][1])
+    W, H, spp, depth = 96, 54, 2, 5
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    ra, fa, _ = make_renderer(a, W, H, max_depth=depth, seed=3, cam=cam)
+    rb, fb, _ = make_renderer(b, W, H, max_depth=depth, seed=3, cam=cam)
+    ra.ProgressiveRender(spp)
+    rb.ProgressiveRender(spp)
+    ra.download()
+    rb.download()
+    assert np.array_equal(fa.accum, fb.accum) and ra.stats().rays_total == rb.stats().rays_total
+
+
+def test_image_parity_instanced_scene_vs_oracle():
+    mesh = prt.scenes.refined("bunny.ply", 12_000)
+    scene = _instanced_scene(mesh, with_world_mesh=True)
+    W, H, spp, depth = 128, 72, 2, 5
+    cam = prt.Camera(position=(6.0, 4.0, 9.0), width=W, height=H)
+    r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=11, cam=cam)
+    r.ProgressiveRender(spp)
+    r.download()
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=11, iterative=True,
+                                                     use_bvh=True, n_threads=8)
+    assert np.array_equal(film.accum, acc) and np.array_equal(film.weights, wts)
+    assert r.stats().rays_total == rays
+    st = r.measure_traversal()
+    assert st.bvh_node_visits > 0 and st.bvh_tri_tests > 0 and st.max_stack_used <= 15
+
+
+def test_instances_must_be_similarity_transforms():
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
+    sc = prt.Scene(preset=None)
+    sc.AddInstance(mesh, sc.AddLambertian((1, 1, 1)), scale=(1.0, 2.0, 1.0))
+    r = prt.HipWavefrontRenderer(device=0)
+    with pytest.raises(prt.PrtError, match="uniform scale"):
+        r.Init(prt.Film(8, 8), sc, prt.Camera(width=8, height=8))
+
+
 def test_cpp_adapter_cli_renders_the_same_image(tmp_path):
     """The C++ host path (prt_render: reference-shaped adapter over the C-ABI, offline framebuffer dump) against the
     oracle: CORNELL 64x64, 2 spp, 3 segments, seed 7 -> PFM of mean radiance, bit-exact."""

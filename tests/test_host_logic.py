@@ -529,6 +529,56 @@ def test_bvh8_python_traversal_agrees_with_oracle_linear_scan():
     assert len(octs) == 8 and max_sp < r.bvh_info().depth8
 
 
+def test_instanced_scene_builds_a_two_level_tree_on_the_host():
+    """PrtInstance: one tree per instanced mesh + a top-level tree over the copies (host-only context)."""
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply")).refine(400)
+    sc = prt.Scene(preset=None)
+    mat = sc.AddLambertian((1, 1, 1))
+    sc.AddMesh(mesh, mat)
+    for k in range(5):
+        sc.AddInstance(mesh, mat, scale=0.5 + 0.25 * k, euler_deg=(10 * k, 25 * k, 0), translation=(3.0 * k, 0.5, -2.0 * k))
+    r = prt.HipWavefrontRenderer(device=-1)
+    r.set_scene_host_only(sc)
+    info = r.bvh_info()
+    one = prt.HipWavefrontRenderer(device=-1)
+    alone = prt.Scene(preset=None)
+    alone.AddMesh(mesh, alone.AddLambertian((1, 1, 1)))
+    one.set_scene_host_only(alone)
+    n_mesh = one.bvh_info().n_nodes8
+    n8 = r.bvh_read8()
+    # [top level over 6 instances][the world meshes' tree][the instanced mesh's tree]: the mesh is stored twice, not 6x
+    assert info.n_nodes8 == len(n8) and 2 * n_mesh < len(n8) <= 2 * n_mesh + 4
+    assert info.n_triangles == 2 * mesh.n_triangles and sc.n_triangles == 6 * mesh.n_triangles
+    assert info.depth8 <= 15
+    D = _decode8(n8)
+    # the top-level root: its leaf "triangles" are the 6 instances (top-level slots 0..5)
+    slots = []
+    stack = [0]
+    n_top = len(n8) - 2 * n_mesh
+    while stack:
+        n = stack.pop()
+        assert n < n_top
+        rank = 0
+        for i in range(8):
+            meta = int(D["meta"][n, i])
+            if meta == 0:
+                continue
+            if (D["imask"][n] >> i) & 1:
+                stack.append(int(D["child_base"][n]) + rank)
+                rank += 1
+            else:
+                cnt = bin(meta >> 5).count("1")
+                first = int(D["tri_base"][n]) + (meta & 31)
+                slots += list(range(first, first + cnt))
+    assert sorted(slots) == list(range(6))
+    # the mesh trees' child / triangle bases were made absolute
+    assert int(D["child_base"][n_top]) > n_top and int(D["tri_base"][n_top + n_mesh]) >= mesh.n_triangles
+    bad = prt.Scene(preset=None)
+    bad.AddInstance(mesh, bad.AddLambertian((1, 1, 1)), scale=(1.0, 2.0, 1.0))
+    with pytest.raises(prt.PrtError, match="uniform scale"):
+        prt.HipWavefrontRenderer(device=-1).set_scene_host_only(bad)
+
+
 # ---- tile map / partition (dist.py restates the kernels' tile layout) ---------------------------------------------------
 @pytest.mark.parametrize("W,H,world", [(64, 48, 1), (100, 52, 3), (37, 19, 2), (1920, 1080, 8), (8, 8, 4)])
 def test_tile_partition_covers_every_pixel_once(W, H, world):
