@@ -35,7 +35,8 @@ PRIM_BYTES = 112       # one analytic primitive record (DevPrim)
 
 
 MESH_OF = {"C2": "bunny.ply refined by longest-edge bisection", "C3": "dragon.ply refined by longest-edge bisection",
-           "C4": "dragon.ply refined by longest-edge bisection", "C5": "12 baked copies of the refined dragon.ply"}
+           "C4": "dragon.ply refined by longest-edge bisection", "C5": "12 baked copies of the refined dragon.ply",
+           "C5I": "12 placed copies (PrtInstance, two-level BVH) of the refined dragon.ply"}
 
 
 def load_traffic(config, world, spp_step, sif, kernel):
@@ -57,7 +58,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md §8d)")
+    ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 | C5I (SURVEY.md §8d; C5I = C5 as placed copies of one mesh)")
     ap.add_argument("--spp-per-step", type=int, default=0, help="0 = the config's full sample count (C3: 256)")
     ap.add_argument("--samples-in-flight", type=int, default=0, help="0 = auto")
     ap.add_argument("--variant", type=int, default=0)

@@ -675,8 +675,8 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
             DevInstance& I = c->dev_insts[i];
             I.root = (n_world && i == 0) ? world_root : blas[I.root].node_base;
         }
-        if (top.depth8 + max_blas_depth > 15u)
-            return fail(c, PRT_ERR_INVALID, "two-level BVH too deep for the traversal stack (%u + %u > 15)", top.depth8, max_blas_depth);
+        if (top.depth8 + max_blas_depth > 12u)
+            return fail(c, PRT_ERR_INVALID, "two-level BVH too deep for the traversal stack (%u + %u > 12)", top.depth8, max_blas_depth);
         // scene-wide quantities the producers use
         for (int a = 0; a < 3; ++a) {
             d.root_min[a] = FLT_MAX;

@@ -1262,6 +1262,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     __shared__ uint32_t s_queue[4 * T8_QCAP];       // per wave: (owner lane << 26) | triangle slot
     __shared__ uint32_t s_qn[8];                    // per wave: [w] items appended so far, [4 + w] first position that did not fit
     __shared__ uint32_t s_iters[8];                 // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
+    __shared__ float s_wray[INST ? 6 * 256 : 1];    // INST: the lane's WORLD ray (origin, raw direction), [component][thread]
     const uint32_t count = *count_ptr;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
@@ -1374,6 +1375,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                             ipm = 0u;
                             lscale = 1.0f;
                             padw4 = 0.0f;
+                            s_wray[0 * 256 + tid] = O.x; s_wray[1 * 256 + tid] = O.y; s_wray[2 * 256 + tid] = O.z;
+                            s_wray[3 * 256 + tid] = D.x; s_wray[4 * 256 + tid] = D.y; s_wray[5 * 256 + tid] = D.z;
                         }
                     }
                 }
@@ -1394,25 +1397,28 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             const bool has = gy > 0x00FFFFFFu;
             if (INST) {
                 const bool enter = !in_blas && ipm != 0u;               // instance hits of the last top-level node first
-                const bool leave = !enter && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
+                const bool leave = in_blas && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
                 if (enter || leave) {
                     if (pending) {  // queued triangles still refer to the current ray: wait for the triangle phase
                         stall = true;
                     } else {
-                        const float4 O = ro[k];
-                        const float4 D = rd[k];
-                        f3 dw = mk3(D.x, D.y, D.z);
-                        o = mk3(O.x, O.y, O.z);
+                        f3 dw = mk3(s_wray[3 * 256 + tid], s_wray[4 * 256 + tid], s_wray[5 * 256 + tid]);
+                        o = mk3(s_wray[0 * 256 + tid], s_wray[1 * 256 + tid], s_wray[2 * 256 + tid]);
                         const float pad_w = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
-                        if (enter) {
+                        // leaving an instance while the same top-level node has more instance hits goes straight into
+                        // the next one (the sentinel stays): no world-ray round trip in between
+                        const bool next = ipm != 0u;
+                        if (next) {
                             inst = sc.tlas_inst[ipb + (uint32_t)__builtin_ctz(ipm)];
                             ipm &= ipm - 1u;
-                            if (has) {  // the remaining top-level siblings wait below the sentinel
-                                s_stack[sp * 256 + tid] = make_uint2(gx, gy);
+                            if (enter) {
+                                if (has) {  // the remaining top-level siblings wait below the sentinel
+                                    s_stack[sp * 256 + tid] = make_uint2(gx, gy);
+                                    ++sp;
+                                }
+                                s_stack[(sp <= STACK_L ? sp : STACK_L) * 256 + tid] = make_uint2(T8_SENTINEL, 0xFF000000u);
                                 ++sp;
                             }
-                            s_stack[(sp <= STACK_L ? sp : STACK_L) * 256 + tid] = make_uint2(T8_SENTINEL, 0xFF000000u);
-                            ++sp;
                             const DevInstance& I = sc.insts[inst];
                             o = transform_point(I.inv, o);      // primitive.cpp:29
                             ld = transform_normal(I.mat, dw);   // primitive.cpp:30
@@ -1440,7 +1446,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
                         octinv4 = octinv * 0x01010101u;
                         tlimit = (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad;
-                        gy = enter ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
+                        gy = next ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
                         if (sp > STACK_L) {  // no room left: give the ray up (an error the host reports)
                             overflow = true;
                             gy = 0u;
@@ -1580,11 +1586,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     const uint32_t slot = item & 0x03FFFFFFu;
                     const f3 qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
                     const f3 qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
-                    uint32_t qinst = 0u, qk = 0u, win = slot;
-                    if (INST) {
-                        qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
-                        qk = (uint32_t)__shfl((int)k, (int)owner, 64);
-                    }
+                    uint32_t qinst = 0u, win = slot;
+                    if (INST) qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
                     bool cand = false;
                     unsigned long long key = 0ull;
                     if (act) {
@@ -1599,8 +1602,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                             uint32_t prim;
                             if (INST) {  // position back through Mat, distance in world space (primitive.cpp:38-43)
                                 const DevInstance& I = sc.insts[qinst];
-                                const float4 OW = ro[qk];
-                                d2 = dist2(mk3(OW.x, OW.y, OW.z), transform_point(I.mat, pos));
+                                const uint32_t oc = wbase + owner;
+                                d2 = dist2(mk3(s_wray[0 * 256 + oc], s_wray[1 * 256 + oc], s_wray[2 * 256 + oc]), transform_point(I.mat, pos));
                                 prim = I.prim_base + __float_as_uint(a.w);
                                 win = I.virt_base + (slot - I.slot_base);
                             } else {
@@ -1938,8 +1941,9 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, false, IN>), grid, block, 0, st, sc, in.o, in.d,      \
                                in.hit, in.hd2, count_ptr, work, ovf, tune, stats);                                 \
     } while (0)
-        if (sc.n_insts) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths)
-            PRT_LAUNCH_8(15, 4, true);
+        if (sc.n_insts) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths).
+            // 12 stack entries + the lanes' world rays in LDS = the same 40 KB per block as the one-level instance
+            PRT_LAUNCH_8(12, 4, true);
             return;
         }
         if (tune.stack_lds == 5u)

@@ -97,4 +97,16 @@ def config(name: str):
                 inst.transform(mat, inv)
                 big = inst if big is None else big.append(inst)
         return mesh_scene(big), Camera(GRID_CAMERA, width=1920, height=1080), 1920, 1080, 1024, 9
+    if name == "C5I":  # the same 12 dragons as placed copies of ONE mesh (PrtInstance, two-level BVH)
+        base = refined("dragon.ply", 870_000)
+        sc = Scene(preset=None)
+        ground = sc.AddLambertian((0.5, 0.5, 0.5))
+        light = sc.AddEmissive((15.0, 15.0, 15.0))
+        body = sc.AddLambertian((0.8, 0.8, 0.8))
+        sc.AddQuad(20.0, 20.0, ground, translation=(0.0, -1.0, 0.0))
+        sc.AddQuad(4.0, 4.0, light, euler_deg=(180.0, 0.0, 0.0), translation=(0.0, 5.0, 0.0))
+        for gz in range(3):
+            for gx in range(4):
+                sc.AddInstance(base, body, translation=((gx - 1.5) * 2.2, 0.0, (gz - 1.0) * 2.2))
+        return sc, Camera(GRID_CAMERA, width=1920, height=1080), 1920, 1080, 1024, 9
     raise ValueError(f"unknown config {name}")

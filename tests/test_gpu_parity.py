@@ -334,7 +334,7 @@ def test_closest_hit_instances_vs_linear_scan_bit_exact(with_world_mesh):
     scene = _instanced_scene(mesh, with_world_mesh)
     r, _, _ = make_renderer(scene, 16, 16)
     info = r.bvh_info()
-    assert info.n_nodes8 > 0 and info.depth8 <= 15
+    assert info.n_nodes8 > 0 and info.depth8 <= 12
     rng = np.random.default_rng(21)
     o, d = util.random_rays(rng, 6000, center=(0, 0.5, 0), radius=11.0, spread=4.5)
     o2 = rng.uniform(-4, 4, size=(3000, 3)).astype(np.float32)
@@ -379,7 +379,7 @@ def test_image_parity_instanced_scene_vs_oracle():
     assert np.array_equal(film.accum, acc) and np.array_equal(film.weights, wts)
     assert r.stats().rays_total == rays
     st = r.measure_traversal()
-    assert st.bvh_node_visits > 0 and st.bvh_tri_tests > 0 and st.max_stack_used <= 15
+    assert st.bvh_node_visits > 0 and st.bvh_tri_tests > 0 and st.max_stack_used <= 12
 
 
 def test_instances_must_be_similarity_transforms():

@@ -549,7 +549,7 @@ def test_instanced_scene_builds_a_two_level_tree_on_the_host():
     # [top level over 6 instances][the world meshes' tree][the instanced mesh's tree]: the mesh is stored twice, not 6x
     assert info.n_nodes8 == len(n8) and 2 * n_mesh < len(n8) <= 2 * n_mesh + 4
     assert info.n_triangles == 2 * mesh.n_triangles and sc.n_triangles == 6 * mesh.n_triangles
-    assert info.depth8 <= 15
+    assert info.depth8 <= 12
     D = _decode8(n8)
     # the top-level root: its leaf "triangles" are the 6 instances (top-level slots 0..5)
     slots = []
