@@ -182,9 +182,15 @@ def main():
         # measured HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (profiles/*_traffic.json, written by tools/pmc_traffic.py); null when no matching profile is committed
         traffic, traffic_note = load_traffic(args.config, world, spp_step, sif, kernel_name)
+        occ = r.kernel_occupancy()
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": kernel_name, "node_bytes": node_bytes,
+                    # static wavefront occupancy of that kernel against the gfx950 limit (32 waves per CU)
+                    "occupancy": {"waves_per_cu": int(occ.waves_per_cu), "max_waves_per_cu": int(occ.max_waves_per_cu),
+                                  "frac": round(occ.waves_per_cu / max(1, occ.max_waves_per_cu), 3), "vgprs": int(occ.vgprs),
+                                  "lds_bytes_per_block": int(occ.lds_bytes_per_block),
+                                  "resident_blocks": int(occ.resident_grid_blocks), "compute_units": int(occ.compute_units)},
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
                     "alg_bytes_per_launch": int(bytes_per_launch),
                     "rays_walked_frac": round(rays_walked / max(1, rays_sample), 3),

@@ -189,6 +189,17 @@ typedef struct PrtBvhInfo {
     uint32_t depth8;       /* levels of the 8-wide tree (the traversal stacks at most depth8 - 1 node groups) */
 } PrtBvhInfo;
 
+/* Static wavefront occupancy of the traversal kernel (the dominant kernel) for the current scene. */
+typedef struct PrtOccupancy {
+    uint32_t blocks_per_cu;        /* resident 256-thread blocks per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) */
+    uint32_t waves_per_cu;         /* = 4 x blocks_per_cu */
+    uint32_t max_waves_per_cu;     /* hardware limit (32 on gfx950) */
+    uint32_t vgprs;                /* per lane */
+    uint32_t lds_bytes_per_block;
+    uint32_t compute_units;
+    uint32_t resident_grid_blocks; /* blocks of the persistent grid the library launches */
+} PrtOccupancy;
+
 typedef struct PrtContext PrtContext;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -258,6 +269,7 @@ int prt_reset_stats(PrtContext* ctx);
  * bvh_node_visits / bvh_tri_tests / prim_tests / rays_per_depth in `out`. */
 int prt_measure_traversal(PrtContext* ctx, uint32_t max_depth, uint32_t seed, uint32_t sample, PrtStats* out);
 int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
+int prt_kernel_occupancy(PrtContext* ctx, PrtOccupancy* out);
 /* Copies the built BVH out (host arrays): nodes n_nodes*16 floats (layout: csrc/bvh.h), tris
  * n_triangles*12 floats in leaf order.  Either pointer may be NULL.  Works on host-only contexts. */
 int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);

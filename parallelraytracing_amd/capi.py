@@ -69,6 +69,12 @@ class PrtStats(C.Structure):
                 ("scan_ms", C.c_double), ("rays_traversed", C.c_uint64), ("tri_lane_slots", C.c_uint64), ("max_stack_used", C.c_uint64)]
 
 
+class PrtOccupancy(C.Structure):
+    _fields_ = [("blocks_per_cu", C.c_uint32), ("waves_per_cu", C.c_uint32), ("max_waves_per_cu", C.c_uint32),
+                ("vgprs", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("compute_units", C.c_uint32),
+                ("resident_grid_blocks", C.c_uint32)]
+
+
 class PrtSampling(C.Structure):
     _fields_ = [("jitter", C.c_uint32), ("rr_depth", C.c_uint32), ("clamp", C.c_float)]
 
@@ -117,6 +123,7 @@ SIGNATURES = {
     "prt_reset_stats": (C.c_int, [_vp]),
     "prt_measure_traversal": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PrtStats)]),
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
+    "prt_kernel_occupancy": (C.c_int, [_vp, C.POINTER(PrtOccupancy)]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),
     "prt_bvh_read4": (C.c_int, [_vp, _fp]),

@@ -1117,6 +1117,25 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     return PRT_OK;
 }
 
+int prt_kernel_occupancy(PrtContext* c, PrtOccupancy* out) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!out) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    int nb = 0, vg = 0, sg = 0, lds = 0;
+    if (prt_traverse_occupancy(c->dsc, &nb, &vg, &sg, &lds)) return fail(c, PRT_ERR_HIP, "occupancy query failed");
+    hipDeviceProp_t prop;
+    HIPCHECK(c, hipGetDeviceProperties(&prop, c->device));
+    out->blocks_per_cu = (uint32_t)nb;
+    out->waves_per_cu = (uint32_t)nb * 4u;  // 256-thread blocks = 4 wave64
+    out->max_waves_per_cu = (uint32_t)(prop.maxThreadsPerMultiProcessor / 64);
+    out->vgprs = (uint32_t)vg;
+    out->lds_bytes_per_block = (uint32_t)lds;
+    out->compute_units = (uint32_t)prop.multiProcessorCount;
+    out->resident_grid_blocks = c->tune.grid_blocks;
+    return PRT_OK;
+}
+
 int prt_bvh_info(PrtContext* c, PrtBvhInfo* out) {
     if (!c || !out) return PRT_ERR_INVALID;
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");

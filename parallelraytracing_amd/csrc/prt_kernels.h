@@ -96,6 +96,7 @@ void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& 
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
                          const PrtTravTuning& tune, unsigned long long* stats);
+int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes);
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                           uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,

@@ -1988,6 +1988,26 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 #undef PRT_LAUNCH_T
 }
 
+// Static occupancy of the default traversal kernel instance for this scene (what the wavefront-occupancy figure of
+// the bench line is computed from): resident 256-thread blocks per CU by the runtime's occupancy calculator, and the
+// kernel's register / LDS footprint.
+int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes) {
+    const void* fn = sc.n_insts ? (const void*)k_traverse8_persistent<12, 4, false, true>
+                     : sc.nodes8 ? (const void*)k_traverse8_persistent<15, 4, false, false>
+                                 : (const void*)k_traverse4_persistent<32, 4, 3, false>;
+    hipFuncAttributes at;
+    hipError_t e = hipFuncGetAttributes(&at, fn);
+    if (e != hipSuccess) return (int)e;
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0);
+    if (e != hipSuccess) return (int)e;
+    *blocks_per_cu = nb;
+    *vgprs = at.numRegs;
+    *sgprs = 0;
+    *lds_bytes = (int)at.sharedSizeBytes;
+    return 0;
+}
+
 // Variants 1 (while-while) and 2 (one-loop): the fused one-thread-per-ray kernel, kept for A/B runs.
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr, uint32_t max_rays, int stack_depth, int variant,
                           unsigned long long* stats) {

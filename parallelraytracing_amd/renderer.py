@@ -447,6 +447,11 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_bvh_info(self._ctx, C.byref(b)))
         return b
 
+    def kernel_occupancy(self):
+        o = capi.PrtOccupancy()
+        self._check(capi.lib().prt_kernel_occupancy(self._ctx, C.byref(o)))
+        return o
+
     def bvh_read(self):
         b = self.bvh_info()
         nodes = np.zeros((b.n_nodes, 16), np.float32)
