@@ -1329,7 +1329,75 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         const bool idle = k == 0xFFFFFFFFu;
         const unsigned long long idle_mask = __ballot(idle);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        if (!exhausted && n_idle >= tune.refill_min) {
+        bool do_sw = false;  // wave-uniform
+        if (INST) {
+            // Level switches (enter the next instance hit of a top-level node / leave an exhausted instance) cost ~150
+            // instructions plus the instance record's gather.  Lanes that need one wait (stall) and the wave does them
+            // together, under the same rule as the refill: when refill_min lanes are idle or waiting.  No lane has
+            // items in the queue here (the triangle phase of the previous iteration emptied it), so the queued
+            // triangles never see a ray other than the one they were found with.
+            const uint32_t n_sw = (uint32_t)__popcll(__ballot(stall));
+            do_sw = n_sw != 0u && n_idle + n_sw >= tune.refill_min;
+            if (do_sw && stall) {
+                const int spr = sp > 0 ? sp - 1 : 0;
+                const bool has = gy > 0x00FFFFFFu;
+                const bool enter = !in_blas;
+                f3 dw = mk3(s_wray[3 * 256 + tid], s_wray[4 * 256 + tid], s_wray[5 * 256 + tid]);
+                o = mk3(s_wray[0 * 256 + tid], s_wray[1 * 256 + tid], s_wray[2 * 256 + tid]);
+                const float pad_w = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                // leaving an instance while the same top-level node has more instance hits goes straight into the
+                // next one (the sentinel stays): no world-ray round trip in between
+                const bool next = ipm != 0u;
+                if (next) {
+                    inst = sc.tlas_inst[ipb + (uint32_t)__builtin_ctz(ipm)];
+                    ipm &= ipm - 1u;
+                    if (enter) {
+                        if (has) {  // the remaining top-level siblings wait below the sentinel
+                            s_stack[sp * 256 + tid] = make_uint2(gx, gy);
+                            ++sp;
+                        }
+                        s_stack[(sp <= STACK_L ? sp : STACK_L) * 256 + tid] = make_uint2(T8_SENTINEL, 0xFF000000u);
+                        ++sp;
+                    }
+                    const DevInstance& I = sc.insts[inst];
+                    o = transform_point(I.inv, o);      // primitive.cpp:29
+                    ld = transform_normal(I.mat, dw);   // primitive.cpp:30
+                    pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + I.extent);
+                    lscale = I.inv_scale * 1.000001f;
+                    padw4 = 4.0f * pad_w;
+                    gx = I.root;
+                    in_blas = true;
+                } else {
+                    sp = spr;  // pop the sentinel
+                    ld = normalize3(dw);
+                    pad = pad_w;
+                    lscale = 1.0f;
+                    padw4 = 0.0f;
+                    gx = 0u;
+                    in_blas = false;
+                }
+                ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+                anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
+                any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
+                anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
+                octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+                octinv4 = octinv * 0x01010101u;
+                tlimit = (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad;
+                gy = next ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
+                if (sp > STACK_L) {  // no room left: give the ray up (an error the host reports)
+                    overflow = true;
+                    gy = 0u;
+                    sp = 0;
+                    ipm = 0u;
+                    in_blas = false;
+                }
+                stall = false;
+            }
+        }
+        if (!exhausted && (n_idle >= tune.refill_min || (INST && do_sw && n_idle != 0u))) {
             if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
                 uint32_t c = 0xFFFFFFFFu;
                 if (lane == 0) c = grab_chunk(work, n_chunks, my_xcd, tune.xcd_affinity != 0u);
@@ -1372,6 +1440,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         sp = 0;
                         if (INST) {
                             in_blas = false;
+                            stall = false;
                             ipm = 0u;
                             lscale = 1.0f;
                             padw4 = 0.0f;
@@ -1398,64 +1467,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             if (INST) {
                 const bool enter = !in_blas && ipm != 0u;               // instance hits of the last top-level node first
                 const bool leave = in_blas && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
-                if (enter || leave) {
-                    if (pending) {  // queued triangles still refer to the current ray: wait for the triangle phase
-                        stall = true;
-                    } else {
-                        f3 dw = mk3(s_wray[3 * 256 + tid], s_wray[4 * 256 + tid], s_wray[5 * 256 + tid]);
-                        o = mk3(s_wray[0 * 256 + tid], s_wray[1 * 256 + tid], s_wray[2 * 256 + tid]);
-                        const float pad_w = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
-                        // leaving an instance while the same top-level node has more instance hits goes straight into
-                        // the next one (the sentinel stays): no world-ray round trip in between
-                        const bool next = ipm != 0u;
-                        if (next) {
-                            inst = sc.tlas_inst[ipb + (uint32_t)__builtin_ctz(ipm)];
-                            ipm &= ipm - 1u;
-                            if (enter) {
-                                if (has) {  // the remaining top-level siblings wait below the sentinel
-                                    s_stack[sp * 256 + tid] = make_uint2(gx, gy);
-                                    ++sp;
-                                }
-                                s_stack[(sp <= STACK_L ? sp : STACK_L) * 256 + tid] = make_uint2(T8_SENTINEL, 0xFF000000u);
-                                ++sp;
-                            }
-                            const DevInstance& I = sc.insts[inst];
-                            o = transform_point(I.inv, o);      // primitive.cpp:29
-                            ld = transform_normal(I.mat, dw);   // primitive.cpp:30
-                            pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + I.extent);
-                            lscale = I.inv_scale * 1.000001f;
-                            padw4 = 4.0f * pad_w;
-                            gx = I.root;
-                            in_blas = true;
-                        } else {
-                            sp = spr;  // pop the sentinel
-                            ld = normalize3(dw);
-                            pad = pad_w;
-                            lscale = 1.0f;
-                            padw4 = 0.0f;
-                            gx = 0u;
-                            in_blas = false;
-                        }
-                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
-                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
-                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
-                        const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
-                        anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
-                        any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
-                        anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
-                        octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-                        octinv4 = octinv * 0x01010101u;
-                        tlimit = (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad;
-                        gy = next ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
-                        if (sp > STACK_L) {  // no room left: give the ray up (an error the host reports)
-                            overflow = true;
-                            gy = 0u;
-                            sp = 0;
-                            ipm = 0u;
-                            in_blas = false;
-                        }
-                    }
-                    walk = tBm == 0u && !stall && ((gy > 0x00FFFFFFu) || sp > 0 || ipm != 0u);
+                if (enter || leave) {  // level switches are done by the whole wave together, next to the refill
+                    stall = true;
+                    walk = false;
                     if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
                     continue;
                 }
@@ -1629,7 +1643,6 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     tlimit = INST ? (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad : limit_from_d2(best.d2, pad);
                 }
                 pending = false;  // everything that was queued has been tested
-                stall = false;
                 q_lanes = 0u;
             }
         }
