@@ -46,11 +46,13 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
 // reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
 // Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
+// `mult` (block-uniform) reserves that many slots per emitting thread: copy j of a thread's ray goes to the returned slot
+// + j * *stride (front) or - j * *stride (back), so that every copy index forms one contiguous, coalesced run.
 template <int BLOCK>
 PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, uint32_t* cntB, uint32_t* cntC,
-                              uint32_t cap) {
+                              uint32_t cap, uint32_t mult = 1u, uint32_t* stride = nullptr) {
     __shared__ uint32_t s_a[BLOCK / 64], s_b[BLOCK / 64], s_c[BLOCK / 64];
-    __shared__ uint32_t s_base_a, s_base_b;
+    __shared__ uint32_t s_base_a, s_base_b, s_tot_a, s_tot_b;
     const unsigned long long ma = __ballot(front), mb = __ballot(back), mc = __ballot(done);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -66,9 +68,11 @@ PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, 
             tb += s_b[w];
             tc += s_c[w];
         }
-        s_base_a = ta ? atomicAdd(cntA, ta) : 0u;
-        s_base_b = tb ? atomicAdd(cntB, tb) : 0u;
+        s_base_a = ta ? atomicAdd(cntA, ta * mult) : 0u;
+        s_base_b = tb ? atomicAdd(cntB, tb * mult) : 0u;
         if (tc) atomicAdd(cntC, tc);  // ray segments finished inside the producer: counted, never stored
+        s_tot_a = ta;
+        s_tot_b = tb;
     }
     __syncthreads();
     uint32_t slot = 0xFFFFFFFFu;
@@ -76,10 +80,12 @@ PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, 
         uint32_t j = s_base_a + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; ++w) j += s_a[w];
         slot = j;
+        if (stride) *stride = s_tot_a;
     } else if (back) {
         uint32_t j = s_base_b + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; ++w) j += s_b[w];
         slot = cap - 1u - j;
+        if (stride) *stride = s_tot_b;
     }
     return slot;
 }
@@ -222,6 +228,42 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
     }
     const uint32_t s0 = blockIdx.y * (uint32_t)RAYGEN_GROUP;
     const uint32_t s1 = (s0 + RAYGEN_GROUP < S) ? s0 + RAYGEN_GROUP : S;
+    if (!JITTER) {
+        // Without jitter whether the pixel's primary ray is stored (front / back) or ends right here does not depend
+        // on the sample: decide once, reserve the slots of all samples of this group with ONE atomic per side per
+        // block, and only the RNG seed and the path id differ per copy.
+        f3 o = o0, d = d0, thr = mk3(1.f, 1.f, 1.f);
+        uint32_t rng = 0, depth = 0, id0 = id00;
+        float d2_0 = d2_00;
+        float4 L0 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // outside the image: no path
+        bool front = false, back = false;
+        if (valid) {
+            front = front0;
+            if (!front) {
+                const int r = advance_path<0, false>(sc, id00, o, d, thr, rng, depth, max_depth, sp, &L0, id0, d2_0);
+                back = r == 2;
+            }
+        }
+        uint32_t stride = 0;
+        const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
+                                                            &CNT_C(counts, 0), n_paths, s1 - s0, &stride);
+        if (in_range) {
+            for (uint32_t sl = s0; sl < s1; ++sl) {
+                const uint32_t i = sl * tm.n_pix_local + pl;  // path id
+                if (slot0 != 0xFFFFFFFFu) {
+                    const uint32_t slot = front ? slot0 + (sl - s0) * stride : slot0 - (sl - s0) * stride;
+                    ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+                    rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
+                    rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                    hit[slot] = id0;
+                    hd2[slot] = d2_0;
+                } else {
+                    rad[i] = L0;  // the path ended with its primary ray (sky / light seen directly), or there is none
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t sl = s0; sl < s1; ++sl) {  // block-uniform trip count
         const uint32_t i = sl * tm.n_pix_local + pl;  // path id
         f3 o = o0, d = d0, thr = mk3(1.f, 1.f, 1.f);
@@ -230,8 +272,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         bool front = false, back = false;
         if (valid) {
             rng = path_seed(pixel, first_sample + sl, seed);
-            front = front0;
-            if (JITTER) {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
+            {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
                 const float u1 = rnd01(rng);
                 const float u2 = rnd01(rng);
                 camera_ray(cam, (float)px + u1, (float)py + u2, o, d);

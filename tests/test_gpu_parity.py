@@ -391,6 +391,17 @@ def test_instances_must_be_similarity_transforms():
         r.Init(prt.Film(8, 8), sc, prt.Camera(width=8, height=8))
 
 
+def test_kernel_occupancy_report():
+    """prt_kernel_occupancy: the static wavefront occupancy bench.py reports next to the roofline."""
+    scene = prt.scenes.mesh_scene(prt.Mesh(prt.scenes.asset("bunny.ply")))
+    r, _, _ = make_renderer(scene, 16, 16)
+    o = r.kernel_occupancy()
+    assert o.max_waves_per_cu == 32 and o.compute_units == 256
+    assert 1 <= o.blocks_per_cu <= 8 and o.waves_per_cu == 4 * o.blocks_per_cu
+    assert 64 <= o.vgprs <= 128 and 30_000 < o.lds_bytes_per_block <= 40_960
+    assert o.resident_grid_blocks == o.blocks_per_cu * o.compute_units  # the persistent grid fills the chip exactly
+
+
 def test_cpp_adapter_cli_renders_the_same_image(tmp_path):
     """The C++ host path (prt_render: reference-shaped adapter over the C-ABI, offline framebuffer dump) against the
     oracle: CORNELL 64x64, 2 spp, 3 segments, seed 7 -> PFM of mean radiance, bit-exact."""
