@@ -187,6 +187,8 @@ typedef struct PrtBvhInfo {
     uint32_t max_stack4;   /* worst-case traversal stack entries of the 4-wide tree */
     uint32_t n_nodes8;     /* compressed 8-wide nodes (80 B each) the default kernel walks; 0 = not available */
     uint32_t depth8;       /* levels of the 8-wide tree (the traversal stacks at most depth8 - 1 node groups) */
+    float build_ms;        /* wall time of the BVH construction (device-side build: without the vertex upload) */
+    uint32_t built_on_device; /* 1: built by the device-side builder (prt_set_param("gpu_build", 1)) */
 } PrtBvhInfo;
 
 /* Static wavefront occupancy of the traversal kernel (the dominant kernel) for the current scene. */
@@ -280,7 +282,8 @@ int prt_bvh_read8(PrtContext* ctx, uint32_t* nodes8);
 /* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
 int prt_set_variant(PrtContext* ctx, int variant);
 /* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "wide" (2 = compressed
- * 8-wide tree, default; 1 = 4-wide; 0 = binary), "stack_lds" (kernel instance). */
+ * 8-wide tree, default; 1 = 4-wide; 0 = binary), "stack_lds" (kernel instance), "gpu_build" (1: the next prt_set_scene
+ * builds the 8-wide tree on the device: Morton-ordered, faster to build, slower to traverse; world-space meshes only). */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */

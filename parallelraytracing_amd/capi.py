@@ -83,7 +83,8 @@ class PrtBvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("max_depth", C.c_uint32),
                 ("max_leaf_size", C.c_uint32), ("sah_cost", C.c_float), ("pad_abs", C.c_float),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("n_nodes4", C.c_uint32), ("max_stack4", C.c_uint32),
-                ("n_nodes8", C.c_uint32), ("depth8", C.c_uint32)]
+                ("n_nodes8", C.c_uint32), ("depth8", C.c_uint32), ("build_ms", C.c_float),
+                ("built_on_device", C.c_uint32)]
 
 
 # numpy dtype mirror of PrtHit (40 bytes)

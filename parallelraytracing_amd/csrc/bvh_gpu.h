@@ -1,0 +1,18 @@
+// bvh_gpu.h — device-side builder of the compressed 8-wide tree (see bvh_gpu.hip, bvh.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+struct PrtGpuBvh {
+    uint32_t* d_nodes8;  // n_nodes x 20 dwords (ownership passes to the caller, hipFree)
+    float4* d_tris;      // 3 x float4 per triangle in the tree's slot order
+    float4* d_nrms;
+    uint32_t n_nodes;
+    uint32_t depth;      // levels of the tree
+};
+
+// d_verts / d_norms: 9 floats per triangle (P0,P1,P2 / N0,N1,N2), d_tri_mat: material per triangle, all on the device.
+// cmin / cmax: bounds of the triangle centroids.  Returns 0 on success (synchronous: the stream is drained).
+int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
+                       uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,6 +20,7 @@
 
 #include "../../include/prt.h"
 #include "bvh.h"
+#include "bvh_gpu.h"
 #include "prt_kernels.h"
 
 namespace {
@@ -48,6 +50,7 @@ struct PrtContext {
     BvhBuild bvh;
     std::vector<float> tri_records;   // 12 floats per triangle, leaf order
     std::vector<float> nrm_records;   // 12 floats per triangle, leaf order
+    double gpu_build_ms = 0.0;
     std::vector<uint32_t> nodes8_all;  // scenes with placed mesh copies: top-level tree + every mesh's tree
     std::vector<DevInstance> dev_insts;
     std::vector<uint32_t> tlas_inst;   // top-level leaf slot -> instance
@@ -94,6 +97,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
+    int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
@@ -300,7 +304,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         const uint32_t* front_count = c->d_counts + (size_t)d * PRT_CNT_STRIDE;
         if (c->dsc.n_nodes) {  // only the front part of the buffer can hit a triangle
             if ((rc = begin_event(c, 1, &ep))) return rc;
-            if (c->variant == 0 || c->dsc.n_insts)  // placed mesh copies: only the two-level 8-wide kernel
+            if (c->variant == 0 || c->dsc.n_insts || !c->dsc.nodes)  // placed copies / device-built trees: the 8-wide kernel only
                 prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
                                     c->bvh.max_stack4, c->tune, trav_stats);
             else
@@ -447,12 +451,65 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
             }
         }
     }
-    if (!bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh))
-        return fail(c, PRT_ERR_INVALID, "BVH deeper than the traversal stack (%u > %u)", c->bvh.max_depth, kMaxStack);
     const uint32_t n_prims = (uint32_t)c->prims.size();
-    c->tri_records.assign(12 * (size_t)n_tris, 0.0f);
-    c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
-    for (size_t slot = 0; slot < (size_t)n_tris; ++slot) {
+    // device-side build (prt_set_param("gpu_build", 1)): Morton-ordered 8-wide tree straight on the GPU (bvh_gpu.hip);
+    // only for world-space meshes on a context with a device; anything else takes the host builder below
+    const bool gpu_build = c->gpu_build && c->has_device && n_tris > 0 && s->n_instances == 0;
+    PrtGpuBvh gb{};
+    const auto t_build0 = std::chrono::steady_clock::now();
+    if (gpu_build) {
+        float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (size_t t = 0; t < (size_t)n_tris; ++t)
+            for (int a = 0; a < 3; ++a) {
+                const float* v = &verts[9 * t];
+                const float lo = std::min(v[a], std::min(v[3 + a], v[6 + a])), hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+                const float cc = 0.5f * lo + 0.5f * hi;
+                cmin[a] = std::min(cmin[a], cc);
+                cmax[a] = std::max(cmax[a], cc);
+            }
+        HIPCHECK(c, hipSetDevice(c->device));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        void *dv = nullptr, *dn = nullptr, *dm = nullptr;
+        HIPCHECK(c, hipMalloc(&dv, verts.size() * 4));
+        HIPCHECK(c, hipMalloc(&dn, norms.size() * 4));
+        HIPCHECK(c, hipMalloc(&dm, tri_mat.size() * 4));
+        HIPCHECK(c, hipMemcpy(dv, verts.data(), verts.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(c, hipMemcpy(dn, norms.data(), norms.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(c, hipMemcpy(dm, tri_mat.data(), tri_mat.size() * 4, hipMemcpyHostToDevice));
+        const auto t_dev0 = std::chrono::steady_clock::now();
+        const int brc = prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, (uint32_t)n_tris,
+                                           n_prims, cmin, cmax, &gb);
+        c->gpu_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count();
+        (void)hipFree(dv);
+        (void)hipFree(dn);
+        (void)hipFree(dm);
+        if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
+        if (gb.depth > 15u) {
+            (void)hipFree(gb.d_nodes8);
+            (void)hipFree(gb.d_tris);
+            (void)hipFree(gb.d_nrms);
+            return fail(c, PRT_ERR_INVALID, "device-built BVH too deep for the traversal stack (%u > 15)", gb.depth);
+        }
+        // host copies for the read-back entry points (prt_bvh_read / prt_bvh_read8); the binary and 4-wide trees of
+        // the A/B kernels are not built in this mode
+        c->bvh = BvhBuild();
+        c->bvh.nodes8.resize(20 * (size_t)gb.n_nodes);
+        c->bvh.depth8 = gb.depth;
+        c->bvh.max_leaf = 3;
+        c->tri_records.assign(12 * (size_t)n_tris, 0.0f);
+        c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
+        HIPCHECK(c, hipMemcpy(c->bvh.nodes8.data(), gb.d_nodes8, c->bvh.nodes8.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(c, hipMemcpy(c->tri_records.data(), gb.d_tris, c->tri_records.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(c, hipMemcpy(c->nrm_records.data(), gb.d_nrms, c->nrm_records.size() * 4, hipMemcpyDeviceToHost));
+    } else if (!bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh)) {
+        return fail(c, PRT_ERR_INVALID, "BVH deeper than the traversal stack (%u > %u)", c->bvh.max_depth, kMaxStack);
+    }
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+    if (!gpu_build) {
+        c->tri_records.assign(12 * (size_t)n_tris, 0.0f);
+        c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
+    }
+    for (size_t slot = 0; !gpu_build && slot < (size_t)n_tris; ++slot) {
         const uint32_t t = c->bvh.order[slot];
         float* r = &c->tri_records[12 * slot];
         float* q = &c->nrm_records[12 * slot];
@@ -477,12 +534,14 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.max_stack4 = c->bvh.max_stack4;
     bi.n_nodes8 = (uint32_t)(c->bvh.nodes8.size() / 20);
     bi.depth8 = c->bvh.depth8;
+    bi.build_ms = (float)(gpu_build ? c->gpu_build_ms : build_ms);
+    bi.built_on_device = gpu_build ? 1u : 0u;
     bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
 
     DevScene& d = c->dsc;
     memset(&d, 0, sizeof(d));
     d.n_prims = n_prims;
-    d.n_nodes = bi.n_nodes;
+    d.n_nodes = gpu_build ? gb.n_nodes : bi.n_nodes;  // "the scene has a BVH" for the producers' classification
     d.n_tris = (uint32_t)n_tris;
     d.pad = kPadCoeff;
     d.extent = extent;
@@ -723,16 +782,24 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     HIPCHECK(c, upload(&c->d_prims, c->prims.data(), c->prims.size() * sizeof(DevPrim)));
     HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
     HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
-    HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
-    HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
+    if (gpu_build) {  // the builder's device arrays are the scene's arrays
+        c->d_nodes8 = gb.d_nodes8;
+        c->d_tris = gb.d_tris;
+        c->d_nrms = gb.d_nrms;
+    } else {
+        HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
+        HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
+    }
     const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
-    if (!n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
+    if (!gpu_build && !n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
     if (!c->dev_insts.empty()) {
         HIPCHECK(c, upload(&c->d_insts, c->dev_insts.data(), c->dev_insts.size() * sizeof(DevInstance)));
         HIPCHECK(c, upload(&c->d_tlas_inst, c->tlas_inst.data(), c->tlas_inst.size() * 4));
     }
-    HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
-    HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
+    if (!gpu_build) {
+        HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
+        HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
+    }
     d.prims = (const DevPrim*)c->d_prims;
     d.mat_rgbs = (const float4*)c->d_mat_rgbs;
     d.mat_type = (const uint32_t*)c->d_mat_type;
@@ -983,7 +1050,7 @@ int prt_closest_hit(PrtContext* c, uint32_t n, const float* origins, const float
     if ((rc = ensure_spill(c))) return rc;
     prt_launch_scan_prims(c->stream, c->dsc, c->rb[0], cnt, c->d_work, n, nullptr);
     if (c->dsc.n_nodes) {
-        if (c->variant == 0 || c->dsc.n_insts)
+        if (c->variant == 0 || c->dsc.n_insts || !c->dsc.nodes)
             prt_launch_traverse(c->stream, c->dsc, c->rb[0], cnt, c->d_work, c->d_spill, n, c->bvh.max_depth,
                                 c->bvh.max_stack4, c->tune, nullptr);
         else
@@ -1175,6 +1242,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;
     else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;
     else if (n == "tri_min" && value >= 1 && value <= 1024) c->tune.tri_min = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;

@@ -1983,7 +1983,7 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((KERNEL<L, W, MODE, false>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,    \
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
-    if ((tune.wide == 2u || sc.n_insts) && sc.nodes8) {
+    if ((tune.wide == 2u || sc.n_insts || !sc.nodes4) && sc.nodes8) {  // (device-built scenes only have the 8-wide tree)
         // default: compressed 8-wide tree; a ray needs at most depth8 - 1 stacked node groups.  15 entries at
         // 4 waves/SIMD or 11 entries at 5 waves/SIMD (tune.stack_lds == 5); deeper rays take the overflow list.
 #define PRT_LAUNCH_8(L, W, IN)                                                                                     \
@@ -2005,8 +2005,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
         else
             PRT_LAUNCH_8(15, 4, false);
 #undef PRT_LAUNCH_8
-        hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
-        PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
+        if (sc.nodes4) {  // overflow list -> the spill-capable 4-wide instance
+            hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+            PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
+        }
     } else if (tune.wide) {
         if (stack4 <= 22 && tune.stack_lds == 24) PRT_LAUNCH_T(k_traverse4_persistent, 22, 6, 0, grid, count_ptr, no_list);
         else if (stack4 <= 27) PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 0, grid, count_ptr, no_list);

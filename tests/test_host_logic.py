@@ -376,22 +376,7 @@ def test_cpp_adapter_cli_builds_and_fails_loudly_without_a_device(tmp_path):
 
 
 # ---- compressed 8-wide tree (bvh.h "BVH8Q"): what the default traversal kernel walks ----------------------------------
-def _decode8(n8):
-    """Fields of the [n, 20] uint32 node array."""
-    p = n8[:, 0:3].copy().view(np.float32).astype(np.float64)
-    eb = np.stack([(n8[:, 3] >> (8 * a)) & 0xFF for a in range(3)], axis=1).astype(np.int64)
-    cell = np.ldexp(1.0, eb - 127)
-    imask = (n8[:, 3] >> 24).astype(np.int64)
-    meta = np.stack([(n8[:, 6 + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.int64)
-
-    def planes(w):  # 8 bytes from words w, w+1
-        return np.stack([(n8[:, w + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.float64)
-    qlo = np.stack([planes(8), planes(10), planes(12)], axis=2)   # [n, child, axis]
-    qhi = np.stack([planes(14), planes(16), planes(18)], axis=2)
-    lo = p[:, None, :] + qlo * cell[:, None, :]
-    hi = p[:, None, :] + qhi * cell[:, None, :]
-    return dict(p=p, imask=imask, meta=meta, lo=lo, hi=hi, child_base=n8[:, 4].astype(np.int64),
-                tri_base=n8[:, 5].astype(np.int64))
+_decode8 = util.decode8
 
 
 @pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("dragon.ply", 60_000)])
@@ -407,54 +392,8 @@ def test_bvh8_structure(ply, target):
     _, tris = r.bvh_read()
     nt = mesh.n_triangles
     assert info.n_nodes8 == len(n8) > 0 and info.max_leaf_size <= 3
-    D = _decode8(n8)
-    V = tris.reshape(nt, 3, 4)[:, :, :3].astype(np.float64)
-    covered = np.zeros(nt, np.int32)
-    seen = np.zeros(len(n8), np.int32)
-    exact_lo = np.full((len(n8), 3), np.inf)
-    exact_hi = np.full((len(n8), 3), -np.inf)
-    level = np.zeros(len(n8), np.int32)
-    level[0] = 1
-    fill = []
-    # children have larger indices than their parent (breadth-first layout): one reverse pass gives exact bounds
-    kids = [[] for _ in range(len(n8))]
-    for n in range(len(n8)):
-        rank, m = 0, 0
-        for i in range(8):
-            meta = int(D["meta"][n, i])
-            inner = (D["imask"][n] >> i) & 1
-            if meta == 0:
-                assert not inner
-                continue
-            m += 1
-            if inner:
-                assert meta == (1 << 5) | (24 + i)
-                c = int(D["child_base"][n]) + rank
-                rank += 1
-                assert n < c < len(n8)
-                seen[c] += 1
-                level[c] = level[n] + 1
-                kids[n].append((i, c))
-            else:
-                unary, off = meta >> 5, meta & 31
-                assert unary in (1, 3, 7) and off + bin(unary).count("1") <= 24
-                cnt = bin(unary).count("1")
-                first = int(D["tri_base"][n]) + off
-                covered[first:first + cnt] += 1
-                P = V[first:first + cnt].reshape(-1, 3)
-                assert (P >= D["lo"][n, i]).all() and (P <= D["hi"][n, i]).all()   # quantized box contains the leaf
-                exact_lo[n] = np.minimum(exact_lo[n], P.min(axis=0))
-                exact_hi[n] = np.maximum(exact_hi[n], P.max(axis=0))
-        fill.append(m)
-    assert (covered == 1).all() and (seen[1:] == 1).all() and seen[0] == 0
-    for n in range(len(n8) - 1, -1, -1):
-        for i, c in kids[n]:
-            # the quantized box of an internal child contains everything below it
-            assert (exact_lo[c] >= D["lo"][n, i]).all() and (exact_hi[c] <= D["hi"][n, i]).all()
-            exact_lo[n] = np.minimum(exact_lo[n], exact_lo[c])
-            exact_hi[n] = np.maximum(exact_hi[n], exact_hi[c])
-    assert np.array_equal(exact_lo[0], V.reshape(-1, 3).min(axis=0)) and np.array_equal(D["p"][0], exact_lo[0])
-    assert info.depth8 == level.max() and info.depth8 <= 16
+    fill, depth = util.check_bvh8(n8, tris)
+    assert info.depth8 == depth and info.depth8 <= 16
     print("bvh8 fill", np.mean(fill), len(n8), info.depth8, np.bincount(fill))
     assert np.mean(fill) > 5.0 or len(n8) < 16   # the collapse fills the nodes
     assert len(n8) * 80 < info.node_bytes / 2 or len(n8) < 16   # far smaller than the 4-wide tree

@@ -51,3 +51,76 @@ def image_l2(a, b):
 
 def cam_desc(position=(5.0, 5.0, 8.0), width=64, height=48, front=None):
     return prt.Camera(position=position, front=front, width=width, height=height)
+
+
+# ---- compressed 8-wide tree (csrc/bvh.h "BVH8Q") ------------------------------------------------------------------------
+def decode8(n8):
+    """Fields of the [n, 20] uint32 node array."""
+    p = n8[:, 0:3].copy().view(np.float32).astype(np.float64)
+    eb = np.stack([(n8[:, 3] >> (8 * a)) & 0xFF for a in range(3)], axis=1).astype(np.int64)
+    cell = np.ldexp(1.0, eb - 127)
+    imask = (n8[:, 3] >> 24).astype(np.int64)
+    meta = np.stack([(n8[:, 6 + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.int64)
+
+    def planes(w):  # 8 bytes from words w, w+1
+        return np.stack([(n8[:, w + (i >> 2)] >> (8 * (i & 3))) & 0xFF for i in range(8)], axis=1).astype(np.float64)
+    qlo = np.stack([planes(8), planes(10), planes(12)], axis=2)   # [n, child, axis]
+    qhi = np.stack([planes(14), planes(16), planes(18)], axis=2)
+    lo = p[:, None, :] + qlo * cell[:, None, :]
+    hi = p[:, None, :] + qhi * cell[:, None, :]
+    return dict(p=p, imask=imask, meta=meta, lo=lo, hi=hi, child_base=n8[:, 4].astype(np.int64),
+                tri_base=n8[:, 5].astype(np.int64))
+
+
+def check_bvh8(n8, tris):
+    """Structural validity of a one-level 8-wide tree over the triangle records `tris` [nt, 12]: every triangle slot in
+    exactly one leaf, internal children contiguous and referenced once, meta bytes well formed, and every quantized
+    child box contains the exact bounds of everything below it.  Returns (children per node, levels)."""
+    nt = len(tris)
+    D = decode8(n8)
+    V = tris.reshape(nt, 3, 4)[:, :, :3].astype(np.float64)
+    covered = np.zeros(nt, np.int32)
+    seen = np.zeros(len(n8), np.int32)
+    exact_lo = np.full((len(n8), 3), np.inf)
+    exact_hi = np.full((len(n8), 3), -np.inf)
+    level = np.zeros(len(n8), np.int32)
+    level[0] = 1
+    fill = []
+    kids = [[] for _ in range(len(n8))]
+    for n in range(len(n8)):  # children have larger indices than their parent
+        rank, m = 0, 0
+        for i in range(8):
+            meta = int(D["meta"][n, i])
+            inner = (D["imask"][n] >> i) & 1
+            if meta == 0:
+                assert not inner
+                continue
+            m += 1
+            if inner:
+                assert meta == (1 << 5) | (24 + i)
+                c = int(D["child_base"][n]) + rank
+                rank += 1
+                assert n < c < len(n8)
+                seen[c] += 1
+                level[c] = level[n] + 1
+                kids[n].append((i, c))
+            else:
+                unary, off = meta >> 5, meta & 31
+                assert unary in (1, 3, 7) and off + bin(unary).count("1") <= 24
+                cnt = bin(unary).count("1")
+                first = int(D["tri_base"][n]) + off
+                covered[first:first + cnt] += 1
+                P = V[first:first + cnt].reshape(-1, 3)
+                assert (P >= D["lo"][n, i]).all() and (P <= D["hi"][n, i]).all()   # quantized box contains the leaf
+                exact_lo[n] = np.minimum(exact_lo[n], P.min(axis=0))
+                exact_hi[n] = np.maximum(exact_hi[n], P.max(axis=0))
+        fill.append(m)
+    assert (covered == 1).all() and (seen[1:] == 1).all() and seen[0] == 0
+    for n in range(len(n8) - 1, -1, -1):
+        for i, c in kids[n]:
+            # the quantized box of an internal child contains everything below it
+            assert (exact_lo[c] >= D["lo"][n, i]).all() and (exact_hi[c] <= D["hi"][n, i]).all()
+            exact_lo[n] = np.minimum(exact_lo[n], exact_lo[c])
+            exact_hi[n] = np.maximum(exact_hi[n], exact_hi[c])
+    assert np.array_equal(exact_lo[0], V.reshape(-1, 3).min(axis=0)) and np.array_equal(D["p"][0], exact_lo[0])
+    return fill, int(level.max())
