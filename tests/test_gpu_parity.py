@@ -391,6 +391,23 @@ def test_instances_must_be_similarity_transforms():
         r.Init(prt.Film(8, 8), sc, prt.Camera(width=8, height=8))
 
 
+def test_headline_frame_one_sample_bit_exact():
+    """BASELINE's headline workload at its FULL size: C3 (870,000 triangles), 1920x1080, max_depth 5, one sample per
+    pixel = 3.7 M ray segments, every pixel compared with the oracle's throughput form (own BVH), plus the ray
+    count; then the same frame rendered as two batches with 64 samples in flight must continue it bit for bit."""
+    scene, cam, W, H, _, depth = prt.scenes.config("C3")
+    r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=0, cam=cam)
+    r.ProgressiveRender(1)
+    r.download()
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=1, max_depth=depth, seed=0, iterative=True,
+                                                     use_bvh=True, n_threads=16)
+    assert np.array_equal(film.weights, wts) and (wts == 1).all()
+    nbad = int((film.accum != acc).any(axis=-1).sum())
+    assert nbad == 0, f"{nbad} of {W * H} pixels differ from the oracle"
+    st = r.stats()
+    assert st.rays_total == rays and st.rays_per_depth[0] == W * H
+
+
 # ---- device-side builder (prt_set_param("gpu_build", 1)) --------------------------------------------------------------
 @pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("bunny.ply", 70_000)])
 def test_device_built_tree_is_valid_and_gives_the_same_hits(ply, target):
