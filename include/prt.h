@@ -172,6 +172,11 @@ typedef struct PrtStats {
     uint64_t rays_traversed;           /* prt_measure_traversal: rays that entered the BVH root box (walked the tree) */
     uint64_t tri_lane_slots;           /* 64 x triangle-loop iterations of all waves: tri tests / slots = lane efficiency */
     uint64_t max_stack_used;           /* deepest traversal stack any ray reached (prt_measure_traversal) */
+    /* prt_measure_traversal, 8-wide kernel: shader cycles (s_memtime) summed over all waves, by section of the wave's
+     * outer loop: finish + refill (+ level switches), node loop, triangle phase */
+    uint64_t wave_cycles_refill;
+    uint64_t wave_cycles_node;
+    uint64_t wave_cycles_tri;
 } PrtStats;
 
 typedef struct PrtBvhInfo {

@@ -66,7 +66,8 @@ class PrtStats(C.Structure):
                 ("intersect_launches", C.c_uint64), ("intersect_ms", C.c_double), ("shade_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("bvh_node_visits", C.c_uint64),
                 ("bvh_tri_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("node_lane_slots", C.c_uint64),
-                ("scan_ms", C.c_double), ("rays_traversed", C.c_uint64), ("tri_lane_slots", C.c_uint64), ("max_stack_used", C.c_uint64)]
+                ("scan_ms", C.c_double), ("rays_traversed", C.c_uint64), ("tri_lane_slots", C.c_uint64), ("max_stack_used", C.c_uint64),
+                ("wave_cycles_refill", C.c_uint64), ("wave_cycles_node", C.c_uint64), ("wave_cycles_tri", C.c_uint64)]
 
 
 class PrtOccupancy(C.Structure):

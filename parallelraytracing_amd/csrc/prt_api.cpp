@@ -97,6 +97,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
+    int measure_spp = 1;  // samples of the instrumented batch of prt_measure_traversal
     int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
@@ -181,10 +182,10 @@ int ensure_counters(PrtContext* c) {
     if (c->d_counts) return PRT_OK;
     HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 8 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 16 * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 8 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 16 * sizeof(unsigned long long)));
     // [0..255] chunk cursors (one 128-B line per XCD), [256] watchdog flag, [512] overflow count, [513..] overflow list
     HIPCHECK(c, hipMalloc((void**)&c->d_work, (513 + (1u << 20)) * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_work, 0, (513 + (1u << 20)) * sizeof(uint32_t)));
@@ -1148,21 +1149,23 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     if (rc) return rc;
     if (!out || max_depth == 0 || max_depth > PRT_MAX_DEPTH) return fail(c, PRT_ERR_INVALID, "bad arguments");
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 8 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 16 * sizeof(unsigned long long)));
     const bool timing = c->timing;
     const uint64_t launches = c->stats.intersect_launches;
     c->timing = false;
     // the per-depth ray counters are cumulative: take this run's share as a difference and put the old values back
     unsigned long long before[PRT_MAX_DEPTH], after[PRT_MAX_DEPTH];
     HIPCHECK(c, hipMemcpy(before, c->d_ray_stats, sizeof(before), hipMemcpyDeviceToHost));
-    rc = run_batch(c, 1, max_depth, seed, sample, false, c->d_trav_stats);
+    // measure_spp (prt_set_param) samples in one batch: the counters scale, the per-phase cycle split becomes that of a
+    // loaded kernel
+    rc = run_batch(c, (uint32_t)std::max(1, c->measure_spp), max_depth, seed, sample, false, c->d_trav_stats);
     c->timing = timing;
     c->stats.intersect_launches = launches;
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     HIPCHECK(c, hipMemcpy(after, c->d_ray_stats, sizeof(after), hipMemcpyDeviceToHost));
     HIPCHECK(c, hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice));
-    unsigned long long t[8];
+    unsigned long long t[16];
     std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
     HIPCHECK(c, hipMemcpy(cnt.data(), c->d_counts, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1174,13 +1177,16 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
         out->rays_total += out->rays_per_depth[d];
     }
     out->rays_traversed = front;
-    out->samples = 1;
+    out->samples = (uint64_t)std::max(1, c->measure_spp);
     out->bvh_node_visits = t[0];
     out->bvh_tri_tests = t[1];
     out->prim_tests = (uint64_t)c->prims.size() * out->rays_total;  // every ray scans every analytic primitive
     out->node_lane_slots = t[3];
     out->tri_lane_slots = t[4];
     out->max_stack_used = t[5];
+    out->wave_cycles_refill = t[6];
+    out->wave_cycles_node = t[7];
+    out->wave_cycles_tri = t[8];
     return PRT_OK;
 }
 
@@ -1242,6 +1248,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;
     else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;
     else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;
     else if (n == "tri_min" && value >= 1 && value <= 1024) c->tune.tri_min = (uint32_t)value;

@@ -1340,6 +1340,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
     bool exhausted = false;         // wave-uniform
     uint32_t q_lanes = 0;           // wave-uniform: lane-steps that queued triangles since the last phase (<= items)
+    // STATS: shader cycles (s_memtime) this wave spent in the three sections of an outer iteration
+    unsigned long long cyc_refill = 0, cyc_node = 0, cyc_tri = 0, t_mark = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
     // idle; every outer iteration makes progress (a node step, a triangle phase or a refill); the iteration cap is
     // a watchdog that turns a would-be hang into an error flag the host reports.
@@ -1497,6 +1499,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             if (exhausted) break;
             continue;
         }
+        if (STATS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            cyc_refill += t - t_mark;
+            t_mark = t;
+        }
         // ---- phase 1: node steps.  Triangles found go straight to the wave's queue and the lane keeps walking;
         // leave when at most exit_max lanes can still walk or enough work for a triangle phase has piled up ----
         bool walk = (k != 0xFFFFFFFFu) && tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u)) && !(INST && stall);
@@ -1607,6 +1614,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             walk = tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u));
             if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
         }
+        if (STATS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            cyc_node += t - t_mark;
+            t_mark = t;
+        }
         // ---- phase 2: the queued (ray, triangle) pairs, one pair per lane per round ----
         {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1687,8 +1699,18 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 q_lanes = 0u;
             }
         }
+        if (STATS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            cyc_tri += t - t_mark;
+            t_mark = t;
+        }
     }
     if (STATS) {
+        if (lane == 0) {
+            atomicAdd(&stats[6], cyc_refill);
+            atomicAdd(&stats[7], cyc_node);
+            atomicAdd(&stats[8], cyc_tri);
+        }
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
         __syncthreads();

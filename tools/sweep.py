@@ -85,10 +85,15 @@ def main():
                 f"scan {stages[name][0]:.2f} trav {stages[name][1]:.2f} shade {stages[name][2]:.2f}")
         if args.eff:
             apply(d)
+            r.set_param("measure_spp", min(64, d["sif"]))
             tr = r.measure_traversal()
+            r.set_param("measure_spp", 1)
             line += (f"  eff {tr.bvh_node_visits / max(1, tr.node_lane_slots):.3f} walked {tr.rays_traversed / tr.rays_total:.3f}"
                      f" tri-eff {tr.bvh_tri_tests / max(1, tr.tri_lane_slots):.3f} maxsp {tr.max_stack_used}"
                      f" nodes/walked {tr.bvh_node_visits / max(1, tr.rays_traversed):.2f} tris/walked {tr.bvh_tri_tests / max(1, tr.rays_traversed):.2f}")
+            tot = max(1, tr.wave_cycles_refill + tr.wave_cycles_node + tr.wave_cycles_tri)
+            line += (f"  wave time: refill {tr.wave_cycles_refill / tot:.2f} node {tr.wave_cycles_node / tot:.2f} tri {tr.wave_cycles_tri / tot:.2f}"
+                     f"  cyc/node-iter {64 * tr.wave_cycles_node / max(1, tr.node_lane_slots):.0f} cyc/tri-iter {64 * tr.wave_cycles_tri / max(1, tr.tri_lane_slots):.0f}")
         print(line, flush=True)
 
 
