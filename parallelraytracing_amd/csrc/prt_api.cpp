@@ -806,6 +806,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.mat_type = (const uint32_t*)c->d_mat_type;
     d.nodes = (const float4*)c->d_nodes;
     d.nodes4 = (const float4*)c->d_nodes4;
+    d.depth8 = bi.depth8;
     d.insts = (const DevInstance*)c->d_insts;
     d.tlas_inst = (const uint32_t*)c->d_tlas_inst;
     d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
@@ -1205,7 +1206,8 @@ int prt_kernel_occupancy(PrtContext* c, PrtOccupancy* out) {
     out->vgprs = (uint32_t)vg;
     out->lds_bytes_per_block = (uint32_t)lds;
     out->compute_units = (uint32_t)prop.multiProcessorCount;
-    out->resident_grid_blocks = c->tune.grid_blocks;
+    out->resident_grid_blocks = (c->dsc.nodes8 && !c->dsc.n_insts && c->dsc.depth8 <= 9u && c->tune.stack_lds == 0u)
+                                    ? c->tune.grid_blocks + c->tune.grid_blocks / 4u : c->tune.grid_blocks;
     return PRT_OK;
 }
 
@@ -1247,7 +1249,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "chunk" && value >= 64 && value % 64 == 0) c->tune.chunk = (uint32_t)value;
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
-    else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;
     else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;
     else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;

@@ -1288,7 +1288,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // non-instanced results bit for bit); a candidate's key is its WORLD distance^2 |o - Mat * pos|^2 and its global
 // primitive index, as in the reference.  A lane changes level only when none of its items is left in the queue.
 #define T8_SENTINEL 0xFFFFFFFFu
-template <int STACK_L, int WAVES, bool STATS, bool INST>
+template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false>
 __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
@@ -1304,6 +1304,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     __shared__ uint32_t s_qn[8];                    // per wave: [w] items appended so far, [4 + w] first position that did not fit
     __shared__ uint32_t s_iters[8];                 // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
     __shared__ float s_wray[INST ? 6 * 256 : 1];    // INST: the lane's WORLD ray (origin, raw direction), [component][thread]
+    // LEAN (5 waves per SIMD: <= 96 VGPRs): what only the triangle phase needs lives in LDS instead of registers: the
+    // lane's ray (origin, unit direction) here, its best key in s_key and its best hit id in s_slot for its whole life
+    __shared__ float s_lray[LEAN ? 6 * 256 : 1];
     const uint32_t count = *count_ptr;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
@@ -1321,7 +1324,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     uint32_t k = 0xFFFFFFFFu;
     f3 o = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
     float ix = 1.f, iy = 1.f, iz = 1.f, anx = 0.f, any = 0.f, anz = 0.f, afx = 0.f, afy = 0.f, afz = 0.f, pad = 0.f, tlimit = 0.f;
-    uint32_t octinv = 7u, octinv4 = 0x07070707u;
+    uint32_t octinv4 = 0x07070707u;  // (7 - direction octant) in every byte
     uint32_t gx = 0u, gy = 0u;    // current node group
     uint32_t tBb = 0u, tBm = 0u;  // a triangle group that did not fit the queue (the lane waits for the next phase)
     bool pending = false;         // this lane has items in the wave's queue
@@ -1365,7 +1368,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 overflow = false;
                 k = 0xFFFFFFFFu;
             } else if (!(gy > 0x00FFFFFFu) && sp == 0) {
-                hit[k] = best.id;
+                hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
                 k = 0xFFFFFFFFu;
             }
         }
@@ -1426,10 +1429,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
                 any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
                 anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
-                octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-                octinv4 = octinv * 0x01010101u;
+                octinv4 = (7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u))) * 0x01010101u;
                 tlimit = (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad;
-                gy = next ? (1u << (24u + octinv)) : 0u;  // the instance's root "group" / nothing pending
+                gy = next ? (1u << (24u + (octinv4 & 7u))) : 0u;  // the instance's root "group" / nothing pending
                 if (sp > STACK_L) {  // no room left: give the ray up (an error the host reports)
                     overflow = true;
                     gy = 0u;
@@ -1471,15 +1473,20 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
                         any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
                         anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
-                        octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-                        octinv4 = octinv * 0x01010101u;
+                        octinv4 = (7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u))) * 0x01010101u;
                         best.id = hid;
                         best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
                         best.d2 = hd2[qi];
                         tlimit = limit_from_d2(best.d2, pad);
+                        if (LEAN) {
+                            s_lray[0 * 256 + tid] = o.x; s_lray[1 * 256 + tid] = o.y; s_lray[2 * 256 + tid] = o.z;
+                            s_lray[3 * 256 + tid] = ld.x; s_lray[4 * 256 + tid] = ld.y; s_lray[5 * 256 + tid] = ld.z;
+                            s_key[tid] = ((unsigned long long)__float_as_uint(best.d2) << 32) | (hid == HIT_MISS ? 0u : hid);
+                            s_slot[tid] = hid;
+                        }
                         k = qi;
                         gx = 0u;  // the root "group": node 0, one pending hit that decodes to slot 0
-                        gy = 1u << (24u + octinv);
+                        gy = 1u << (24u + (octinv4 & 7u));
                         sp = 0;
                         if (INST) {
                             in_blas = false;
@@ -1529,7 +1536,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             cy &= ~(1u << bit);
             s_stack[sp * 256 + tid] = make_uint2(cx, cy);  // the remaining siblings (kept only if there are any)
             sp += (cy > 0x00FFFFFFu) ? 1 : 0;
-            const uint32_t slot = (bit - 24u) ^ octinv;
+            const uint32_t slot = (bit - 24u) ^ (octinv4 & 7u);
             const uint32_t idx = cx + (uint32_t)__popc(cy & ((1u << slot) - 1u));  // bits 0..7 of cy: imask
             const uint4* nb = sc.nodes8 + 5 * (size_t)idx;
             const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
@@ -1638,8 +1645,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 }
                 // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
                 const unsigned long long key_best =
-                    ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
-                s_key[tid] = key_best;
+                    LEAN ? 0ull : ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
+                if (!LEAN) s_key[tid] = key_best;
                 if (lane == 0) {
                     s_qn[wv] = 0u;
                     s_qn[4 + wv] = T8_QCAP;
@@ -1651,8 +1658,15 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     const uint32_t item = ((volatile uint32_t*)queue)[act ? kq : 0u];
                     const uint32_t owner = act ? (item >> 26) : lane;
                     const uint32_t slot = item & 0x03FFFFFFu;
-                    const f3 qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
-                    const f3 qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                    f3 qo, qd;
+                    if (LEAN) {
+                        const uint32_t oc = wbase + owner;
+                        qo = mk3(s_lray[0 * 256 + oc], s_lray[1 * 256 + oc], s_lray[2 * 256 + oc]);
+                        qd = mk3(s_lray[3 * 256 + oc], s_lray[4 * 256 + oc], s_lray[5 * 256 + oc]);
+                    } else {
+                        qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
+                        qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                    }
                     uint32_t qinst = 0u, win = slot;
                     if (INST) qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
                     bool cand = false;
@@ -1685,11 +1699,13 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     }
                     if (STATS && lane == 0) ++s_iters[4 + wv];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = win;
+                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = LEAN ? sc.n_prims + win : win;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
                 const unsigned long long won = ((volatile unsigned long long*)s_key)[tid];
-                if (won != key_best) {
+                if (LEAN) {
+                    tlimit = limit_from_d2(__uint_as_float((uint32_t)(won >> 32)), pad);  // same value if nothing changed
+                } else if (won != key_best) {
                     best.d2 = __uint_as_float((uint32_t)(won >> 32));
                     best.prim = (uint32_t)won;
                     best.id = sc.n_prims + ((volatile uint32_t*)s_slot)[tid];
@@ -2022,10 +2038,23 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             PRT_LAUNCH_8(12, 4, true);
             return;
         }
-        if (tune.stack_lds == 5u)
+        // default: the 5-waves-per-SIMD instance (96 VGPRs: ray and best hit live in LDS, 8 stack entries) for trees of
+        // at most 9 levels (C3: 9), else the 4-waves instance with 15 entries (C5: 11 levels); stack_lds 4 / 5 / 6
+        // force one for A/B runs
+        const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && sc.depth8 <= 9u);
+        if (tune.stack_lds == 5u) {
             PRT_LAUNCH_8(11, 5, false);
-        else
+        } else if (lean) {
+            const dim3 grid5(g == tune.grid_blocks ? g + g / 4u : g);  // 5 instead of 4 resident blocks per CU
+            if (stats)
+                hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true>), grid5, block, 0, st, sc, in.o, in.d,
+                                   in.hit, in.hd2, count_ptr, work, ovf, tune, stats);
+            else
+                hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true>), grid5, block, 0, st, sc, in.o, in.d,
+                                   in.hit, in.hd2, count_ptr, work, ovf, tune, stats);
+        } else {
             PRT_LAUNCH_8(15, 4, false);
+        }
 #undef PRT_LAUNCH_8
         if (sc.nodes4) {  // overflow list -> the spill-capable 4-wide instance
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
@@ -2071,6 +2100,7 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 // kernel's register / LDS footprint.
 int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes) {
     const void* fn = sc.n_insts ? (const void*)k_traverse8_persistent<12, 4, false, true>
+                     : (sc.nodes8 && sc.depth8 <= 9u) ? (const void*)k_traverse8_persistent<8, 5, false, false, true>
                      : sc.nodes8 ? (const void*)k_traverse8_persistent<15, 4, false, false>
                                  : (const void*)k_traverse4_persistent<32, 4, 3, false>;
     hipFuncAttributes at;

@@ -131,7 +131,7 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
     assert info.n_nodes8 > 0 and info.depth8 <= 16
     # every tunable / kernel instance gives the same hits: the compressed 8-wide tree (default, wide = 2) at both
     # occupancies, the 4-wide tree's instances (wide = 1), the binary tree (wide = 0)
-    for wide, name, val in ((2, "stack_lds", 5), (2, "chunk", 64), (2, "xcd_affinity", 1), (2, "exit_max", 0), (2, "refill_min", 1),
+    for wide, name, val in ((2, "stack_lds", 4), (2, "stack_lds", 5), (2, "stack_lds", 6), (2, "chunk", 64), (2, "xcd_affinity", 1), (2, "exit_max", 0), (2, "refill_min", 1),
                             (1, "stack_lds", 0), (1, "stack_lds", 1), (1, "stack_lds", 2), (1, "stack_lds", 3),
                             (1, "stack_lds", 39), (1, "xcd_affinity", 1), (1, "chunk", 64), (0, "stack_lds", 0)):
         r.set_param("wide", wide)
