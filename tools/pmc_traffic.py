@@ -23,6 +23,15 @@ ap.add_argument("--kernel", default="k_traverse4_persistent")
 args = ap.parse_args()
 
 
+def instrumented(name):
+    """The STATS = true instances (prt_measure_traversal): k_traverse8_persistent<L, W, STATS, INST[, LEAN]>,
+    k_traverse4_persistent<L, W, MODE, STATS>."""
+    if "<" not in name:
+        return False
+    a = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    return (a[2] if "traverse8" in name else a[-1]) == "true"
+
+
 def total(d, counter):
     """Counter sum and dispatch count of the DOMINANT instance of the kernel (the template instance with the
     largest sum: the overflow-list re-traversal and the instrumented instance are separate, tiny dispatches)."""
@@ -30,7 +39,7 @@ def total(d, counter):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
-            if args.kernel in name and r["Counter_Name"] == counter and "true>" not in name:
+            if args.kernel in name and r["Counter_Name"] == counter and not instrumented(name):
                 s[name] += float(r["Counter_Value"])
                 n[name].add(r["Dispatch_Id"])
     if not s:
