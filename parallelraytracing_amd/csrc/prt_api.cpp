@@ -1206,7 +1206,7 @@ int prt_kernel_occupancy(PrtContext* c, PrtOccupancy* out) {
     out->vgprs = (uint32_t)vg;
     out->lds_bytes_per_block = (uint32_t)lds;
     out->compute_units = (uint32_t)prop.multiProcessorCount;
-    out->resident_grid_blocks = (c->dsc.nodes8 && !c->dsc.n_insts && c->dsc.depth8 <= 9u && c->tune.stack_lds == 0u)
+    out->resident_grid_blocks = (c->dsc.nodes8 && !c->dsc.n_insts && (c->dsc.depth8 <= 9u || c->dsc.nodes4) && c->tune.stack_lds == 0u)
                                     ? c->tune.grid_blocks + c->tune.grid_blocks / 4u : c->tune.grid_blocks;
     return PRT_OK;
 }

@@ -2041,7 +2041,9 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
         // default: the 5-waves-per-SIMD instance (96 VGPRs: ray and best hit live in LDS, 8 stack entries) for trees of
         // at most 9 levels (C3: 9), else the 4-waves instance with 15 entries (C5: 11 levels); stack_lds 4 / 5 / 6
         // force one for A/B runs
-        const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && sc.depth8 <= 9u);
+        // (deeper host-built trees: rays that need more than 8 entries go through the overflow list to the 4-wide
+        // spill-capable instance; C5, 11 levels: deepest stack 8, no such ray)
+        const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && (sc.depth8 <= 9u || sc.nodes4 != nullptr));
         if (tune.stack_lds == 5u) {
             PRT_LAUNCH_8(11, 5, false);
         } else if (lean) {
@@ -2100,7 +2102,7 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 // kernel's register / LDS footprint.
 int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes) {
     const void* fn = sc.n_insts ? (const void*)k_traverse8_persistent<12, 4, false, true>
-                     : (sc.nodes8 && sc.depth8 <= 9u) ? (const void*)k_traverse8_persistent<8, 5, false, false, true>
+                     : (sc.nodes8 && (sc.depth8 <= 9u || sc.nodes4)) ? (const void*)k_traverse8_persistent<8, 5, false, false, true>
                      : sc.nodes8 ? (const void*)k_traverse8_persistent<15, 4, false, false>
                                  : (const void*)k_traverse4_persistent<32, 4, 3, false>;
     hipFuncAttributes at;
