@@ -59,6 +59,27 @@ def test_scene_validation_errors():
         r.set_scene_host_only(bad)
     with pytest.raises(prt.PrtError):
         prt.Mesh(vertices=np.zeros((3, 3), np.float32), indices=np.array([[0, 1, 7]], np.uint32))
+    # sampling options and tunables are validated as well
+    with pytest.raises(prt.PrtError, match="bad sampling"):
+        r.set_sampling(jitter=2)
+    with pytest.raises(prt.PrtError, match="bad sampling"):
+        r.set_sampling(clamp=-1.0)
+    r.set_sampling(jitter=1, rr_depth=3, clamp=4.0)
+    r.set_sampling()
+    for name, bad_value in (("wide", 3), ("fuse", 2), ("gpu_build", 5), ("tri_min", 0), ("chunk", 100), ("nonsense", 1)):
+        with pytest.raises(prt.PrtError, match="unknown parameter or bad value"):
+            r.set_param(name, bad_value)
+    # an instance that points at a mesh that is not there
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
+    sc = prt.Scene(preset=None)
+    sc.AddInstance(mesh, sc.AddLambertian((1, 1, 1)))
+    sc.instances[0].mesh = 7
+    with pytest.raises(prt.PrtError, match="mesh out of range"):
+        r.set_scene_host_only(sc)
+    sc.instances[0].mesh = 0
+    sc.instances[0].material_id = 9
+    with pytest.raises(prt.PrtError, match="material out of range"):
+        r.set_scene_host_only(sc)
 
 
 # ---- presets / transforms: product host code == oracle restatement, bit for bit -------------------------------------
