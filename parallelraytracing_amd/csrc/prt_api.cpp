@@ -54,6 +54,7 @@ struct PrtContext {
     std::vector<uint32_t> nodes8_all;  // scenes with placed mesh copies: top-level tree + every mesh's tree
     std::vector<DevInstance> dev_insts;
     std::vector<uint32_t> tlas_inst;   // top-level leaf slot -> instance
+    BvhBuild abvh;                     // BVH over the analytic primitives' world boxes (scenes with many of them)
     PrtBvhInfo bvh_info{};
     DevScene dsc{};
     void* d_prims = nullptr;
@@ -64,6 +65,8 @@ struct PrtContext {
     void* d_nodes8 = nullptr;
     void* d_insts = nullptr;
     void* d_tlas_inst = nullptr;
+    void* d_abvh_nodes = nullptr;
+    void* d_abvh_order = nullptr;
     void* d_tris = nullptr;
     void* d_nrms = nullptr;
 
@@ -97,6 +100,7 @@ struct PrtContext {
     PrtStats stats{};
     uint64_t dead_paths = 0;
     int variant = 0;
+    int abvh_enabled = 1;  // prt_set_param("prim_bvh", 0): keep the reference's linear scan over the analytic primitives
     int measure_spp = 1;  // samples of the instrumented batch of prt_measure_traversal
     int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
     PrtSampling sampling{0u, 0u, 0.0f};
@@ -221,6 +225,8 @@ void free_scene(PrtContext* c) {
     free_dev(c->d_nodes8);
     free_dev(c->d_insts);
     free_dev(c->d_tlas_inst);
+    free_dev(c->d_abvh_nodes);
+    free_dev(c->d_abvh_order);
     free_dev(c->d_tris);
     free_dev(c->d_nrms);
     c->has_scene = false;
@@ -555,6 +561,66 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         d.root_min[t % 3] = std::min(d.root_min[t % 3], verts[t]);
         d.root_max[t % 3] = std::max(d.root_max[t % 3], verts[t]);
     }
+    // ---- BVH over the analytic primitives (only when there are many: the reference scans all of them for every ray,
+    // primitive.cpp:26; its default scene RANDOM_BALLS_LARGE has 809).  World boxes are only valid bounds of the
+    // reference's hits when the primitive's transform is rotation + uniform scale + translation; one primitive that is
+    // not keeps the linear scan for the whole scene. ----
+    c->abvh = BvhBuild();
+    float extent_prims = 0.0f;
+    if (c->abvh_enabled && n_prims > 16u) {
+        std::vector<float> pv(9 * (size_t)n_prims);
+        bool ok = true;
+        for (uint32_t i = 0; i < n_prims && ok; ++i) {
+            const PrtPrimitive& p = s->primitives[i];
+            const float* M = p.mat;
+            double g[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    g[a][b] = (double)M[4 * a] * M[4 * b] + (double)M[4 * a + 1] * M[4 * b + 1] + (double)M[4 * a + 2] * M[4 * b + 2];
+            const double s2 = g[0][0];
+            ok = s2 > 1e-20 && std::isfinite(s2) && M[3] == 0.0f && M[7] == 0.0f && M[11] == 0.0f && M[15] == 1.0f;
+            for (int a = 0; a < 3 && ok; ++a)
+                for (int b = 0; b < 3; ++b)
+                    if (std::fabs(g[a][b] - (a == b ? s2 : 0.0)) > 1e-4 * s2) ok = false;
+            if (!ok) break;
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            if (p.shape_type == PRT_SHAPE_CIRCLE) {  // sphere of radius r around the local origin
+                const double R = std::fabs((double)p.shape_param[0]) * std::sqrt(s2);
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = (float)((double)M[12 + a] - R);
+                    mx[a] = (float)((double)M[12 + a] + R);
+                }
+            } else {  // quad in the local plane y = 0
+                for (int corner = 0; corner < 4; ++corner) {
+                    const float lx = ((corner & 1) ? 0.5f : -0.5f) * p.shape_param[0], lz = ((corner & 2) ? 0.5f : -0.5f) * p.shape_param[1];
+                    for (int a = 0; a < 3; ++a) {
+                        const float wv = (M[a] * lx + M[4 + a] * 0.0f) + (M[8 + a] * lz + M[12 + a]);
+                        mn[a] = std::min(mn[a], wv);
+                        mx[a] = std::max(mx[a], wv);
+                    }
+                }
+            }
+            float mag = 0.0f;
+            for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+            const float slack = 1e-5f * (mag + (float)std::sqrt(s2) * (std::fabs(p.shape_param[0]) + std::fabs(p.shape_param[1]))) + 1e-30f;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] -= slack;
+                mx[a] += slack;
+                if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) ok = false;
+                extent_prims = std::max(extent_prims, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+            }
+            const float tri[9] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], mn[0], mx[1], mn[2]};  // spans the box
+            memcpy(&pv[9 * (size_t)i], tri, sizeof(tri));
+        }
+        if (ok && (!bvh_build(pv.data(), n_prims, kMaxLeaf, 1, kMaxStack, &c->abvh) || c->abvh.nodes4.empty()))  // (a walk that would need more than ABVH_STACK entries falls back to the scan)
+            ok = false;
+        if (!ok) c->abvh = BvhBuild();
+    }
+    if (!c->abvh.nodes4.empty()) {
+        extent = std::max(extent, extent_prims);  // the culling pad of the primitive walk scales with the scene
+        d.extent = extent;
+    }
+
     // ---- placed mesh copies (PrtInstance): one tree per instanced mesh in its own space + a top-level tree over the
     // copies' world boxes; the world-space meshes above become one identity instance ----
     c->nodes8_all.clear();
@@ -793,6 +859,10 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     }
     const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
     if (!gpu_build && !n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
+    if (!c->abvh.nodes4.empty()) {
+        HIPCHECK(c, upload(&c->d_abvh_nodes, c->abvh.nodes4.data(), c->abvh.nodes4.size() * 4));
+        HIPCHECK(c, upload(&c->d_abvh_order, c->abvh.order.data(), c->abvh.order.size() * 4));
+    }
     if (!c->dev_insts.empty()) {
         HIPCHECK(c, upload(&c->d_insts, c->dev_insts.data(), c->dev_insts.size() * sizeof(DevInstance)));
         HIPCHECK(c, upload(&c->d_tlas_inst, c->tlas_inst.data(), c->tlas_inst.size() * 4));
@@ -806,6 +876,8 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.mat_type = (const uint32_t*)c->d_mat_type;
     d.nodes = (const float4*)c->d_nodes;
     d.nodes4 = (const float4*)c->d_nodes4;
+    d.abvh_nodes = (const float4*)c->d_abvh_nodes;
+    d.abvh_order = (const uint32_t*)c->d_abvh_order;
     d.depth8 = bi.depth8;
     d.insts = (const DevInstance*)c->d_insts;
     d.tlas_inst = (const uint32_t*)c->d_tlas_inst;
@@ -1250,6 +1322,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;
     else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;
     else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;

@@ -46,6 +46,10 @@ struct DevScene {
     const uint4* nodes8;        // 5 x uint4 per compressed 8-wide node (see bvh.h); null if the tree has none
     const float4* tris;         // 3 x float4 per triangle, leaf order: {P0, prim}, {P1, material}, {P2, 0}
     const float4* tri_normals;  // 3 x float4 per triangle, leaf order
+    // BVH over the ANALYTIC primitives' world boxes (scenes with many of them, e.g. the RANDOM_BALLS presets: the
+    // reference scans all of them per ray, primitive.cpp:26): 4-wide nodes in the bvh.h layout, leaf slot -> primitive
+    const float4* abvh_nodes;   // null: the producers scan the primitives linearly
+    const uint32_t* abvh_order;
     const DevInstance* insts;   // placed mesh copies; with n_insts > 0 nodes8 starts with a top-level tree over them
     const uint32_t* tlas_inst;  // top-level leaf slot -> instance index
     uint32_t n_insts;

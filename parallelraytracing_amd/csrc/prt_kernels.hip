@@ -105,6 +105,7 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 // ---------------------------------------------------------------------------------------------------------
 // Ray generation (GenerateCameraRaysKernel, renderer.cu:186-204; pixel centres, cpu/renderer.cpp:45)
 // ---------------------------------------------------------------------------------------------------------
+template <bool ABVH, int BLOCK>
 __device__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0);
 __device__ bool ends_here(const DevScene& sc, bool front, uint32_t id0, f3 thr, f3& L);
 
@@ -136,7 +137,7 @@ PRT_DEV float4 path_result(f3 L, float clamp, uint32_t depth) {
     return make_float4(L.x, L.y, L.z, __uint_as_float(depth));
 }
 
-template <int BUDGET, bool INST>
+template <int BUDGET, bool INST, bool ABVH, int BLOCK>
 PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr, uint32_t& rng, uint32_t& depth,
                          uint32_t max_depth, const PrtSampling& sp, float4* __restrict__ rad_slot, uint32_t& id0,
                          float& d2_0) {
@@ -186,7 +187,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             thr = mk3(thr.x / p, thr.y / p, thr.z / p);
         }
         ++depth;
-        if (classify_ray(sc, o, d, id0, d2_0)) return 1;
+        if (classify_ray<ABVH, BLOCK>(sc, o, d, id0, d2_0)) return 1;
         id = id0;
     }
     return 2;  // not reached
@@ -198,7 +199,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 #define RAYGEN_GROUP 8
 // SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
 // which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
-template <bool JITTER, bool SAMPLING>
+template <bool JITTER, bool SAMPLING, bool ABVH>
 __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t S,
                                                             uint32_t first_sample, uint32_t seed,
                                                             float4* __restrict__ ro, float4* __restrict__ rd,
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             pixel = py * tm.W + px;
             if (!JITTER) {  // pixel centre, the same ray for every sample (cpu/renderer.cpp:45)
                 camera_ray(cam, (float)px + 0.5f, (float)py + 0.5f, o0, d0);
-                front0 = classify_ray(sc, o0, d0, id00, d2_00);
+                front0 = classify_ray<ABVH, PRODUCER_BLOCK>(sc, o0, d0, id00, d2_00);
             }
         }
     }
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         if (valid) {
             front = front0;
             if (!front) {
-                const int r = advance_path<0, false>(sc, id00, o, d, thr, rng, depth, max_depth, sp, &L0, id0, d2_0);
+                const int r = advance_path<0, false, ABVH, PRODUCER_BLOCK>(sc, id00, o, d, thr, rng, depth, max_depth, sp, &L0, id0, d2_0);
                 back = r == 2;
             }
         }
@@ -276,10 +277,10 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 const float u1 = rnd01(rng);
                 const float u2 = rnd01(rng);
                 camera_ray(cam, (float)px + u1, (float)py + u2, o, d);
-                front = classify_ray(sc, o, d, id0, d2_0);
+                front = classify_ray<ABVH, PRODUCER_BLOCK>(sc, o, d, id0, d2_0);
             }
             if (!front) {
-                const int r = advance_path<0, false>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
+                const int r = advance_path<0, false, ABVH, PRODUCER_BLOCK>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
                 front = r == 1;
                 back = r == 2;
             }
@@ -309,34 +310,109 @@ struct Closest {
     uint32_t prim;  // global primitive index (tie-break key)
 };
 
-PRT_DEV void scan_analytic(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t& n_tests) {
-    for (uint32_t i = 0; i < sc.n_prims; ++i) {
-        WorldHit w;
-        analytic_hit(sc.prims[i], o, d, w);
-        ++n_tests;
-        if (w.has && w.d2 < best.d2) {  // strict <, first wins (primitive.cpp:44)
-            best.d2 = w.d2;
-            best.id = i;
-            best.prim = i;
-        }
-    }
-}
-
 PRT_DEV float limit_from_d2(float d2, float pad) {
     // Upper bound on the local ray parameter of anything that could still win (d2' <= d2).
     return (d2 < 3.0e38f) ? __builtin_sqrtf(d2) * 1.0000153f + 4.0f * pad : 3.4e38f;
 }
 
+#define ABVH_STACK 20  // entries of the primitive walk's stack (4-wide tree: at most 3 net pushes per level)
+// Closest hit over the analytic primitives.  ABVH = false: the reference's linear scan (primitive.cpp:26-49).
+// ABVH = true: a per-thread walk of a 4-wide BVH over the primitives' WORLD boxes (valid because every primitive of
+// the scene has a rotation + uniform scale + translation transform, checked on the host: only then is the reference's
+// local ray, primitive.cpp:29-30, the geometric ray and the hit lies inside the shape's world box).  Each primitive
+// the walk reaches is tested with the reference's own arithmetic and candidates compete on (d2, primitive index), so
+// the result equals the linear scan's bit for bit whatever the visiting order.
+template <bool ABVH, int BLOCK = 1>
+PRT_DEV void scan_analytic(const DevScene& sc, f3 o, f3 d, Closest& best, uint32_t& n_tests) {
+    if (!ABVH) {
+        for (uint32_t i = 0; i < sc.n_prims; ++i) {
+            WorldHit w;
+            analytic_hit(sc.prims[i], o, d, w);
+            ++n_tests;
+            if (w.has && w.d2 < best.d2) {  // strict <, first wins (primitive.cpp:44)
+                best.d2 = w.d2;
+                best.id = i;
+                best.prim = i;
+            }
+        }
+        return;
+    }
+    const f3 ld = normalize3(d);
+    const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+    const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+    const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+    const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+    const float ax = (o.x + pad) * ix, ay = (o.y + pad) * iy, az = (o.z + pad) * iz;
+    const float bx = (o.x - pad) * ix, by = (o.y - pad) * iy, bz = (o.z - pad) * iz;
+    float tlimit = limit_from_d2(best.d2, pad);
+    // per-thread stack in LDS, [entry][thread] (bank = lane: conflict-free): as a register array it costs 60 VGPRs
+    __shared__ uint32_t s_astk[ABVH ? ABVH_STACK * BLOCK : 1];
+    uint32_t* const stk = &s_astk[threadIdx.x];
+    const uint32_t sstride = (uint32_t)BLOCK;
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const float4* nb = sc.abvh_nodes + 8 * (size_t)node;
+        const float4 mnx = nb[0], mxx = nb[1], mny = nb[2], mxy = nb[3], mnz = nb[4], mxz = nb[5], rf = nb[6];
+#define ABVH_CHILD(C)                                                                                              \
+    {                                                                                                              \
+        const float x0 = __builtin_fmaf(mnx.C, ix, -ax), x1 = __builtin_fmaf(mxx.C, ix, -bx);                      \
+        const float y0 = __builtin_fmaf(mny.C, iy, -ay), y1 = __builtin_fmaf(mxy.C, iy, -by);                      \
+        const float z0 = __builtin_fmaf(mnz.C, iz, -az), z1 = __builtin_fmaf(mxz.C, iz, -bz);                      \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),        \
+                                         __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));                          \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),        \
+                                         __builtin_fminf(__builtin_fmaxf(z0, z1), tlimit));                        \
+        if (tn <= tf * 1.0000005f) {                                                                               \
+            const int ref = __float_as_int(rf.C);                                                                  \
+            if (ref >= 0) {                                                                                        \
+                stk[(sp++) * sstride] = (uint32_t)ref;                                                             \
+            } else {                                                                                               \
+                const uint32_t lr = ~(uint32_t)ref, first = lr >> 4, cnt = lr & 15u;                               \
+                for (uint32_t k = 0; k < cnt; ++k) {                                                               \
+                    const uint32_t i = sc.abvh_order[first + k];                                                   \
+                    WorldHit w;                                                                                    \
+                    analytic_hit(sc.prims[i], o, d, w);                                                            \
+                    ++n_tests;                                                                                     \
+                    if (w.has && (w.d2 < best.d2 || (w.d2 == best.d2 && best.id != HIT_MISS && i < best.prim))) {  \
+                        best.d2 = w.d2;                                                                            \
+                        best.id = i;                                                                               \
+                        best.prim = i;                                                                             \
+                        tlimit = limit_from_d2(best.d2, pad);                                                      \
+                    }                                                                                              \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+        if (sp + 4 > ABVH_STACK) {  // cannot happen for the trees the host builds; stay correct anyway
+            best.d2 = 3.402823466e+38f;
+            best.id = HIT_MISS;
+            best.prim = 0xFFFFFFFFu;
+            scan_analytic<false, 1>(sc, o, d, best, n_tests);
+            return;
+        }
+        ABVH_CHILD(x)
+        ABVH_CHILD(y)
+        ABVH_CHILD(z)
+        ABVH_CHILD(w)
+#undef ABVH_CHILD
+        if (sp == 0) break;
+        node = stk[(--sp) * sstride];
+    }
+}
+
+
 // What every producer does for the ray it emits: the linear scan over the analytic primitives (its result is the
 // initial "best" of the traversal) and the decision whether the BVH has to be walked at all: only if the ray enters
 // the (per-ray padded) root box before the analytic hit, by the same conservative test the traversal applies.
+template <bool ABVH, int BLOCK>
 __device__ __forceinline__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uint32_t& id0, float& d2_0) {
     Closest best;
     best.d2 = 3.402823466e+38f;  // FLT_MAX (primitive.cpp:23)
     best.id = HIT_MISS;
     best.prim = 0xFFFFFFFFu;
     uint32_t n_tests = 0;
-    scan_analytic(sc, o, d, best, n_tests);
+    scan_analytic<ABVH, BLOCK>(sc, o, d, best, n_tests);
     id0 = best.id;
     d2_0 = best.d2;
     if (sc.n_nodes == 0u) return false;
@@ -606,7 +682,7 @@ __global__ void __launch_bounds__(256) k_intersect(DevScene sc, const float4* __
             best.d2 = 3.402823466e+38f;  // FLT_MAX (primitive.cpp:23)
             best.id = HIT_MISS;
             best.prim = 0xFFFFFFFFu;
-            scan_analytic(sc, o, d, best, n_ptests);
+            scan_analytic<false>(sc, o, d, best, n_ptests);
             if (sc.n_nodes) traverse<STACK, STATS, VARIANT>(sc, o, d, best, &s_stack[threadIdx.x], n_nodes, n_tris);
             hit[k] = best.id;
         }
@@ -642,7 +718,10 @@ __global__ void __launch_bounds__(256) k_scan_prims(DevScene sc, const float4* _
     if (D.x == 0.0f && D.y == 0.0f && D.z == 0.0f) {
         best.id = HIT_DEAD;
     } else {
-        scan_analytic(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), best, n_ptests);
+        if (sc.abvh_nodes)
+            scan_analytic<true, 256>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), best, n_ptests);
+        else
+            scan_analytic<false>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), best, n_ptests);
     }
     hit[k] = best.id;
     hd2[k] = best.d2;
@@ -1742,7 +1821,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-template <int FUSE, bool SAMPLING, bool INST>
+template <int FUSE, bool SAMPLING, bool INST, bool ABVH>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
@@ -1775,7 +1854,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
         if (id != HIT_DEAD) {
             o = mk3(O.x, O.y, O.z);
             d = mk3(D.x, D.y, D.z);
-            const int r = advance_path<1 + FUSE, INST>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
+            const int r = advance_path<1 + FUSE, INST, ABVH, SHADE_BLOCK>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
             front = r == 1;
             back = r == 2;
         }
@@ -1979,14 +2058,16 @@ void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
                        uint32_t* work, uint32_t max_depth, const PrtSampling& sp) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
     const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
-#define PRT_RAYGEN(J, SA)                                                                                           \
-    hipLaunchKernelGGL((k_raygen<J, SA>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed, out.o, \
-                       out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp)
+#define PRT_RAYGEN(J, SA, AB)                                                                                       \
+    hipLaunchKernelGGL((k_raygen<J, SA, AB>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed,  \
+                       out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp)
     const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
-    if (sp.jitter) {
-        if (sa) PRT_RAYGEN(true, true); else PRT_RAYGEN(true, false);
+    if (sc.abvh_nodes) {  // many analytic primitives: the general instances with the BVH scan
+        if (sp.jitter) PRT_RAYGEN(true, true, true); else PRT_RAYGEN(false, true, true);
+    } else if (sp.jitter) {
+        if (sa) PRT_RAYGEN(true, true, false); else PRT_RAYGEN(true, false, false);
     } else {
-        if (sa) PRT_RAYGEN(false, true); else PRT_RAYGEN(false, false);
+        if (sa) PRT_RAYGEN(false, true, false); else PRT_RAYGEN(false, false, false);
     }
 #undef PRT_RAYGEN
 }
@@ -2139,16 +2220,18 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
                       uint32_t fuse_max, const PrtSampling& sp) {
     const dim3 grid((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK));
-#define PRT_SHADE(F, SA, IN)                                                                                        \
-    hipLaunchKernelGGL((k_shade<F, SA, IN>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o,     \
+#define PRT_SHADE(F, SA, IN, AB)                                                                                    \
+    hipLaunchKernelGGL((k_shade<F, SA, IN, AB>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, \
                        out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
     const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
-    if (sc.n_insts) {  // scenes with placed mesh copies: one general instance
-        PRT_SHADE(0, true, true);
+    if (sc.abvh_nodes) {  // many analytic primitives: general instances with the BVH scan
+        if (sc.n_insts) PRT_SHADE(0, true, true, true); else PRT_SHADE(0, true, false, true);
+    } else if (sc.n_insts) {  // scenes with placed mesh copies: one general instance
+        PRT_SHADE(0, true, true, false);
     } else if (fuse_max) {
-        if (sa) PRT_SHADE(1, true, false); else PRT_SHADE(1, false, false);
+        if (sa) PRT_SHADE(1, true, false, false); else PRT_SHADE(1, false, false, false);
     } else {
-        if (sa) PRT_SHADE(0, true, false); else PRT_SHADE(0, false, false);
+        if (sa) PRT_SHADE(0, true, false, false); else PRT_SHADE(0, false, false, false);
     }
 #undef PRT_SHADE
 }

@@ -306,6 +306,33 @@ def test_image_parity_with_sampling_upgrades(kind, jitter, rr_depth, clamp):
     assert np.array_equal(film.accum, acc0)
 
 
+@pytest.mark.parametrize("preset", ["RANDOM_BALLS_MEDIUM", "RANDOM_BALLS_LARGE"])
+def test_many_analytic_primitives_bvh_scan_equals_the_linear_scan(preset):
+    """Scenes with more than 16 analytic primitives (the reference's default scene has 809 and scans all of them for
+    every ray, primitive.cpp:26) walk a BVH over the primitives' world boxes inside the producers: same closest hits
+    and same image as the reference's linear scan (oracle), and as the product's own linear scan (prim_bvh = 0)."""
+    scene = prt.Scene(preset)
+    W, H, spp, depth = 96, 54, 2, 8
+    r, film, cam = make_renderer(scene, W, H, max_depth=depth, seed=5)
+    rng = np.random.default_rng(41)
+    o, d = util.random_rays(rng, 4000)
+    got = r.closest_hit(o, d)
+    want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
+    assert util.hits_equal(got, want) == [] and (got["prim"] >= 0).sum() > 2000
+    r.ProgressiveRender(spp)
+    r.download()
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=5, iterative=True,
+                                                     n_threads=8)
+    assert np.array_equal(film.accum, acc) and r.stats().rays_total == rays
+    r2 = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=5)
+    r2.set_param("prim_bvh", 0)
+    f2 = prt.Film(W, H)
+    r2.Init(f2, scene, cam)
+    r2.ProgressiveRender(spp)
+    r2.download()
+    assert np.array_equal(f2.accum, film.accum)
+
+
 # ---- placed mesh copies (PrtInstance): two-level traversal ----------------------------------------------------------------
 INST_PLACEMENTS = [(1.0, (0, 0, 0), (0, 2.6, 0)), (0.5, (0, 40, 0), (2.5, 0, 0)), (1.5, (30, 0, 0), (-3, 0.5, -1)),
                    (0.8, (10, 70, 25), (0, 0.3, 3)), (2.0, (0, 180, 0), (4.0, 1.0, -4.0))]
