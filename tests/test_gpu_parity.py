@@ -409,6 +409,24 @@ def test_image_parity_instanced_scene_vs_oracle():
     assert st.bvh_node_visits > 0 and st.bvh_tri_tests > 0 and st.max_stack_used <= 12
 
 
+def test_placed_copies_next_to_many_analytic_primitives():
+    """Both acceleration structures at once: 109 analytic primitives (primitive BVH in the producers) + placed copies of
+    a mesh (two-level tree in the traversal kernel), jittered and with roulette: image bit-exact vs the oracle."""
+    scene = prt.Scene("RANDOM_BALLS_SMALL")
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply")).refine(600)
+    body = scene.AddMetal((0.9, 0.7, 0.5), 0.2)
+    scene.AddInstance(mesh, body, scale=1.5, euler_deg=(0, 30, 0), translation=(0.0, 1.6, 0.0))
+    scene.AddInstance(mesh, body, scale=0.7, euler_deg=(45, 0, 20), translation=(3.0, 0.8, 1.0))
+    W, H, spp, depth = 96, 54, 2, 6
+    r, film, cam = make_renderer(scene, W, H, max_depth=depth, seed=13)
+    sp = r.set_sampling(jitter=1, rr_depth=2)
+    r.ProgressiveRender(spp)
+    r.download()
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=13, iterative=True,
+                                                     use_bvh=True, n_threads=8, sampling=sp)
+    assert np.array_equal(film.accum, acc) and r.stats().rays_total == rays
+
+
 def test_instances_must_be_similarity_transforms():
     mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
     sc = prt.Scene(preset=None)
