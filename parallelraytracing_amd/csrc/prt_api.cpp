@@ -106,7 +106,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -1322,6 +1322,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;
     else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;

@@ -1387,6 +1387,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // lane's ray (origin, unit direction) here, its best key in s_key and its best hit id in s_slot for its whole life
     __shared__ float s_lray[LEAN ? 6 * 256 : 1];
     const uint32_t count = *count_ptr;
+    // (tune.stack_cap: test hook that makes the stack look shorter, to exercise the overflow path)
+    const int stack_cap = (tune.stack_cap != 0u && tune.stack_cap < (uint32_t)STACK_L) ? (int)tune.stack_cap : STACK_L;
     const uint32_t chunk = tune.chunk;
     const uint32_t n_chunks = (count + chunk - 1u) / chunk;
     const uint32_t my_xcd = xcc_id();
@@ -1672,7 +1674,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             gx = w1.x;
             gy = (hitmask & 0xFF000000u) | (eim >> 24);
             const uint32_t tm = hitmask & 0x00FFFFFFu;
-            if (sp > STACK_L) {  // give the ray up; it is re-traversed through the overflow list
+            if (sp > stack_cap) {  // give the ray up; it is re-traversed through the overflow list
                 overflow = true;
                 gy = 0u;
                 sp = 0;

@@ -142,6 +142,14 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
     r.set_param("wide", 2)
     st = r.measure_traversal()
     assert st.max_stack_used < info.depth8 and st.bvh_node_visits > 0
+    # the overflow path of the 8-wide kernel ("never happens": the stack covers the tree): with the stack capped at 3
+    # entries most rays are handed to the spill-capable 4-wide instance through the overflow list -- same hits
+    for inst in (0, 4):
+        r.set_param("stack_lds", inst)
+        r.set_param("stack_cap", 3)
+        assert util.hits_equal(r.closest_hit(o, d), want) == [], inst
+        r.set_param("stack_cap", 0)
+    r.set_param("stack_lds", 0)
 
 
 def test_scatter_bit_exact_all_materials():
