@@ -1,5 +1,4 @@
 """Shared helpers of the test-suite: scene construction, the oracle side, comparisons."""
-import ctypes as C
 import os
 import sys
 
