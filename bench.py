@@ -10,7 +10,7 @@ max_depth = 5 segments ("4 bounces"), synthetic (there is no 1M-triangle scene i
 A "step" is one complete frame of the config: all its samples per pixel (C3: 256 spp; --spp-per-step overrides)
 over the whole image, followed by the per-frame gather of the ranks' tiles to rank 0 and the un-tiling into the
 Film layout.  The frame is FIXED as N grows (the image is tiled across the GPUs), so scaling is "strong"; every
-GPU keeps up to ~265 M paths in flight (min(spp, 128 x N) samples of its 1/N of the pixels; 34 GB of path state).
+GPU keeps up to ~530 M paths in flight (min(spp, 256 x N) samples of its 1/N of the pixels; 68 GB of path state).
 Rays = ray segments for which a closest-hit query ran, counted on the device.
 The scene, BVH and path state are resident in HBM before the timed region starts.
 """
@@ -113,9 +113,9 @@ def main():
     n_tris = scene.n_triangles
     bvh = r.bvh_info()
     spp_step = args.spp_per_step or spp_total  # a step = one complete frame of the config
-    # many samples in flight: the late bounces are latency/tail-bound, more rays per launch hide it (measured on C3:
-    # 4 -> 3.8, 32 -> 9.0, 64 -> 9.6, 128 -> 10.0, 256 -> 10.2 Grays/s); 288 GB of HBM make 34 GB of path state cheap
-    sif = args.samples_in_flight or min(spp_step, max(1, (128 * 1920 * 1080 * world) // (W * H)))
+    # many samples in flight: the late bounces are latency/tail-bound, more rays per launch hide it (measured on C3 with
+    # the current kernels: 64 -> 13.5, 128 -> 14.2, 256 -> 14.3 Grays/s); 288 GB of HBM make 68 GB of path state cheap
+    sif = args.samples_in_flight or min(spp_step, max(1, (256 * 1920 * 1080 * world) // (W * H)))
     sif = max(1, min(sif, spp_step))
     r.set_samples_in_flight(sif)
     gather = prt.dist.FilmGather(r, device)
