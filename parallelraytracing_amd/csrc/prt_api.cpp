@@ -106,7 +106,9 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u};
+    uint32_t* h_counts = nullptr;  // pinned: the front / back ray counts of each bounce as the host learns them
+    hipEvent_t ev_counts[PRT_MAX_DEPTH + 2] = {};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
@@ -298,6 +300,21 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     // the scene has a BVH and few analytic primitives; with many of them (RANDOM_BALLS presets) compacting between
     // bounces is the better deal
     const uint32_t fuse = (c->dsc.n_nodes && c->dsc.n_prims <= 16u) ? c->tune.fuse : 0u;
+    // The ray count of a bounce is only known on the device.  With big batches a k_shade grid sized for the worst case is
+    // a million blocks, most of which find nothing to do (~0.5 ms per launch, 4 % of a C3 step).  The host therefore
+    // reads the counts of bounce d back WHILE the traversal kernel of bounce d runs (the copy is enqueued right after
+    // the producer that wrote them, the host waits for it after enqueueing the traversal): the GPU never waits for the
+    // host, k_shade gets an exact grid, and a batch stops at the first bounce without rays.
+    const bool exact = c->dsc.n_nodes != 0u && c->tune.exact_grids != 0u && (n_paths > (16384u * 512u) || c->tune.exact_grids == 2u);  // 2: always (tests)
+    if (exact && !c->h_counts) {
+        HIPCHECK(c, hipHostMalloc((void**)&c->h_counts, (PRT_MAX_DEPTH + 2) * 64 * sizeof(uint32_t), hipHostMallocDefault));
+        for (hipEvent_t& e : c->ev_counts) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    auto read_back = [&](uint32_t d) -> hipError_t {  // counts of bounce d: words 0 (front) and 32 (back) of its stride
+        hipError_t e = hipMemcpyAsync(c->h_counts + 64 * (size_t)d, c->d_counts + (size_t)d * PRT_CNT_STRIDE, 33 * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, c->stream);
+        return e != hipSuccess ? e : hipEventRecord(c->ev_counts[d], c->stream);
+    };
     EventPair ep{};
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
@@ -305,6 +322,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     prt_launch_raygen(c->stream, c->dsc, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts,
                       c->d_work, max_depth, c->sampling);
     if ((rc = end_event(c, &ep))) return rc;
+    if (exact) HIPCHECK(c, read_back(0));
     for (uint32_t d = 0; d < max_depth; ++d) {
         const PrtRayBuf& in = c->rb[d & 1];
         const PrtRayBuf& out = c->rb[(d + 1) & 1];
@@ -319,9 +337,17 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             if ((rc = end_event(c, &ep))) return rc;
             ++c->stats.intersect_launches;
         }
+        uint32_t n_rays_known = 0xFFFFFFFFu;
+        if (exact) {
+            HIPCHECK(c, hipEventSynchronize(c->ev_counts[d]));
+            n_rays_known = c->h_counts[64 * (size_t)d] + c->h_counts[64 * (size_t)d + 32];
+            if (n_rays_known == 0u) break;  // every path has ended: the later bounces have nothing to do
+        }
         if ((rc = begin_event(c, 2, &ep))) return rc;
-        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling);
+        prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling,
+                         n_rays_known);
         if ((rc = end_event(c, &ep))) return rc;
+        if (exact && d + 1 < max_depth) HIPCHECK(c, read_back(d + 1));
     }
     // film += the batch's samples (unless this is a measurement run) and per-depth ray counts from the paths' last
     // segment indices
@@ -377,6 +403,10 @@ void prt_destroy(PrtContext* c) {
         free_dev(c->d_counts);
         free_dev(c->d_ray_stats);
         free_dev(c->d_trav_stats);
+        if (c->h_counts) {
+            (void)hipHostFree(c->h_counts);
+            for (hipEvent_t& e : c->ev_counts) (void)hipEventDestroy(e);
+        }
         free_dev(c->d_work);
         free_dev(c->d_spill);
         free_dev(c->d_scratch);
@@ -1322,6 +1352,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "xcd_affinity" && (value == 0 || value == 1)) c->tune.xcd_affinity = (uint32_t)value;
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
+    else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;

@@ -82,6 +82,7 @@ struct PrtTravTuning {
     uint32_t fuse;         // k_shade: 1 = shade one analytic-only segment in place per call (default), 0 = store every ray
     uint32_t stack_cap;    // test hook: the 8-wide kernel treats its stack as this many entries (0 = all of them)
     uint32_t stack_lds;    // selects the kernel instance (stack entries in LDS / waves per SIMD), see prt_launch_traverse
+    uint32_t exact_grids;  // host: size k_shade's grid from the bounce's ray count read back during the traversal (big batches)
 };
 
 struct PrtRayBuf {
@@ -107,7 +108,7 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
                           uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max, const PrtSampling& sp);
+                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats);
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,

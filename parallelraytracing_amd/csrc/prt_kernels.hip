@@ -2220,8 +2220,10 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max, const PrtSampling& sp) {
-    const dim3 grid((uint32_t)((cap + SHADE_BLOCK - 1) / SHADE_BLOCK));
+                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known) {
+    // n_rays_known: the ray count of this bounce if the host has it already (0xFFFFFFFF: size the grid for `cap`)
+    const uint32_t n_for_grid = n_rays_known == 0xFFFFFFFFu ? cap : (n_rays_known ? n_rays_known : 1u);
+    const dim3 grid((uint32_t)((n_for_grid + SHADE_BLOCK - 1) / SHADE_BLOCK));
 #define PRT_SHADE(F, SA, IN, AB)                                                                                    \
     hipLaunchKernelGGL((k_shade<F, SA, IN, AB>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, \
                        out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
