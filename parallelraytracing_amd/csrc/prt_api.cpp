@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,7 @@ namespace {
 
 constexpr float kPadCoeff = 1.0f / 262144.0f;  // 2^-18, see traverse() in prt_kernels.hip
 constexpr uint32_t kMaxLeaf = 3;  // the compressed 8-wide node encodes at most 3 triangles per leaf (bvh.h)
+constexpr uint32_t kTravStatsWords = 16 + PRT_TIMELINE_WORDS * (PRT_MAX_DEPTH + 1);  // counters + one launch timeline per bounce
 constexpr uint32_t kMaxStack = 63;  // LDS stack entries per lane: 31 (5 blocks/CU) or 63 (2 blocks/CU)
 
 struct EventPair {
@@ -106,7 +108,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u};
     uint32_t* h_counts = nullptr;  // pinned: the front / back ray counts of each bounce as the host learns them
     hipEvent_t ev_counts[PRT_MAX_DEPTH + 2] = {};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
@@ -188,10 +190,10 @@ int ensure_counters(PrtContext* c) {
     if (c->d_counts) return PRT_OK;
     HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, 16 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, kTravStatsWords * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 16 * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, kTravStatsWords * sizeof(unsigned long long)));
     // [0..255] chunk cursors (one 128-B line per XCD), [256] watchdog flag, [512] overflow count, [513..] overflow list
     HIPCHECK(c, hipMalloc((void**)&c->d_work, (513 + (1u << 20)) * sizeof(uint32_t)));
     HIPCHECK(c, hipMemset(c->d_work, 0, (513 + (1u << 20)) * sizeof(uint32_t)));
@@ -329,9 +331,12 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         const uint32_t* front_count = c->d_counts + (size_t)d * PRT_CNT_STRIDE;
         if (c->dsc.n_nodes) {  // only the front part of the buffer can hit a triangle
             if ((rc = begin_event(c, 1, &ep))) return rc;
-            if (c->variant == 0 || c->dsc.n_insts || !c->dsc.nodes)  // placed copies / device-built trees: the 8-wide kernel only
+            if (c->variant == 0 || c->dsc.n_insts || !c->dsc.nodes) {  // placed copies / device-built trees: the 8-wide kernel only
+                PrtTravTuning tune = c->tune;
+                tune.probe_slot = d;
                 prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
-                                    c->bvh.max_stack4, c->tune, trav_stats);
+                                    c->bvh.max_stack4, tune, trav_stats);
+            }
             else
                 prt_launch_intersect(c->stream, c->dsc, in, front_count, n_paths, stack_depth, c->variant, trav_stats);
             if ((rc = end_event(c, &ep))) return rc;
@@ -1252,7 +1257,11 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     if (rc) return rc;
     if (!out || max_depth == 0 || max_depth > PRT_MAX_DEPTH) return fail(c, PRT_ERR_INVALID, "bad arguments");
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    HIPCHECK(c, hipMemset(c->d_trav_stats, 0, 16 * sizeof(unsigned long long)));
+    {
+        std::vector<unsigned long long> init(kTravStatsWords, 0ull);
+        for (uint32_t d = 0; d <= PRT_MAX_DEPTH; ++d) init[16 + PRT_TIMELINE_WORDS * d] = init[16 + PRT_TIMELINE_WORDS * d + 2] = ~0ull;  // minima
+        HIPCHECK(c, hipMemcpy(c->d_trav_stats, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    }
     const bool timing = c->timing;
     const uint64_t launches = c->stats.intersect_launches;
     c->timing = false;
@@ -1268,9 +1277,20 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     HIPCHECK(c, hipMemcpy(after, c->d_ray_stats, sizeof(after), hipMemcpyDeviceToHost));
     HIPCHECK(c, hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice));
-    unsigned long long t[16];
+    unsigned long long t[kTravStatsWords];
     std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
+    if (getenv("PRT_TAIL_PROBE")) {  // diagnostic: where a launch of the 8-wide kernel spends its wall time (100 MHz ticks -> us)
+        for (uint32_t d = 0; d < max_depth; ++d) {
+            const unsigned long long* tl = t + 16 + PRT_TIMELINE_WORDS * d;
+            if (tl[6] == 0ull) continue;
+            fprintf(stderr,
+                    "[prt tail probe] bounce %u: launch %.1f us, first wave out of rays at %.1f us, last at %.1f us, drain after "
+                    "the first %.1f us; per wave: mean life %.1f us, mean drain %.1f us (%llu waves); longest ray %llu node steps\n",
+                    d, (tl[1] - tl[0]) * 0.01, (tl[2] - tl[0]) * 0.01, (tl[3] - tl[0]) * 0.01, (tl[1] - tl[2]) * 0.01,
+                    tl[5] * 0.01 / tl[6], tl[4] * 0.01 / tl[6], tl[6], tl[7]);
+        }
+    }
     HIPCHECK(c, hipMemcpy(cnt.data(), c->d_counts, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     uint64_t front = 0;
@@ -1353,6 +1373,8 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "wide" && (value == 0 || value == 1 || value == 2)) c->tune.wide = (uint32_t)value;
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
+    else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
+    else if (n == "tail" && value >= 0 && value <= 64) c->tune.tail = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;

@@ -76,14 +76,23 @@ struct PrtTravTuning {
     uint32_t chunk;        // rays a wave grabs per global atomic (multiple of 64)
     uint32_t refill_min;   // idle lanes of a wave that trigger a refill
     uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf
-    uint32_t xcd_affinity; // 1: each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
+    uint32_t xcd_affinity; // 4-wide / binary kernels, A/B: 1 = each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
     uint32_t wide;         // 2: walk the compressed 8-wide tree (default), 1: the 4-wide tree, 0: the binary tree
     uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles
     uint32_t fuse;         // k_shade: 1 = shade one analytic-only segment in place per call (default), 0 = store every ray
     uint32_t stack_cap;    // test hook: the 8-wide kernel treats its stack as this many entries (0 = all of them)
     uint32_t stack_lds;    // selects the kernel instance (stack entries in LDS / waves per SIMD), see prt_launch_traverse
     uint32_t exact_grids;  // host: size k_shade's grid from the bounce's ray count read back during the traversal (big batches)
+    uint32_t steal;        // 8-wide kernel at 5 waves/SIMD: a draining wave with at least this many idle lanes lets them take pending subtrees of its remaining rays (0 = off)
+    uint32_t tail;         // 8-wide kernel: the last `tail` 64-ray granules per resident wave are handed out one at a time
+    uint32_t probe_slot;   // instrumented instance only: this launch's timeline goes to stats[16 + 8 * probe_slot ..] (see PRT_TIMELINE)
 };
+
+// Timeline of one launch of the instrumented 8-wide kernel, in s_memrealtime ticks (100 MHz), 8 words per launch:
+// (of XCD 0's waves:) [0] first wave start (min), [1] last wave end (max), [2] / [3] first / last wave to find the ray buffer exhausted,
+// [4] sum over waves of (end - exhausted) = wave time spent draining, [5] sum over waves of (end - start), [6] waves,
+// [7] node steps of the longest ray
+#define PRT_TIMELINE_WORDS 8
 
 struct PrtRayBuf {
     float4* o;      // origin.xyz, path id

@@ -1386,11 +1386,34 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // LEAN (5 waves per SIMD: <= 96 VGPRs): what only the triangle phase needs lives in LDS instead of registers: the
     // lane's ray (origin, unit direction) here, its best key in s_key and its best hit id in s_slot for its whole life
     __shared__ float s_lray[LEAN ? 6 * 256 : 1];
+    // STEAL (LEAN instance, only while a wave drains, i.e. after the ray buffer is exhausted).  A launch ends with its
+    // longest rays: C3's take ~130 node steps against a mean of 10, and a launch of 1 k rays lasts as long as one of
+    // 260 k (tools/launch_floor.py: 170 vs 320 us), ~250 us per bounce during which the chip is almost idle.  Idle
+    // lanes of a draining wave therefore take over pending subtrees of the wave's remaining rays: a thief copies the
+    // ray's constants out of the donor's registers, takes the donor's BOTTOM stack entry (the oldest, usually largest
+    // pending node group) and walks it as a helper of the ray's ROOT lane: its triangle tests resolve into the root's
+    // key / slot (the queue item names the root as owner), so helper and root share one culling bound and no merge is
+    // needed; the root writes its hit once its own walk is over and no helper of it is left.  The closest hit does
+    // not depend on the order of the tests, so results stay bit-identical.
+    // (No LDS for the bookkeeping: one more KB would cost the fifth block per CU.  Which roots still have helpers is a
+    // wave-uniform 64-bit mask rebuilt from the helpers' k every outer iteration of a draining wave.)
+    constexpr bool STEAL = LEAN && !INST;
     const uint32_t count = *count_ptr;
     // (tune.stack_cap: test hook that makes the stack look shorter, to exercise the overflow path)
     const int stack_cap = (tune.stack_cap != 0u && tune.stack_cap < (uint32_t)STACK_L) ? (int)tune.stack_cap : STACK_L;
-    const uint32_t chunk = tune.chunk;
-    const uint32_t n_chunks = (count + chunk - 1u) / chunk;
+    // Guided hand-out of the ray buffer, in granules of 64 rays.  The bulk goes out in chunks of tune.chunk rays (one
+    // global atomic per chunk; coherent neighbours stay together), but the last tune.tail granules per resident wave go out
+    // one at a time: otherwise a wave that grabs a full chunk just before the buffer runs dry works four more rounds
+    // (~160 us on C3) while the rest of the chip idles, a fixed cost per launch that hurts most when the frame is split
+    // over 8 GPUs.  Small launches consist of single granules only.  A wave's FIRST grab needs no atomic (grab number =
+    // its index in the grid; 5120 simultaneous atomics on one word take ~60 us); the cursor counts the grabs after it.
+    const uint32_t gran_per_chunk = tune.chunk >> 6;
+    const uint32_t n_gran = (count + 63u) >> 6;
+    const uint32_t n_wv = gridDim.x * 4u;
+    const uint32_t tail_want = n_wv * tune.tail;
+    const uint32_t n_bulk = (n_gran - (tail_want < n_gran ? tail_want : n_gran)) / gran_per_chunk;  // chunks
+    const uint32_t n_grabs = n_bulk + (n_gran - n_bulk * gran_per_chunk);
+    bool first_grab = true;  // wave-uniform
     const uint32_t my_xcd = xcc_id();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = lane_id();
@@ -1426,6 +1449,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     uint32_t q_lanes = 0;           // wave-uniform: lane-steps that queued triangles since the last phase (<= items)
     // STATS: shader cycles (s_memtime) this wave spent in the three sections of an outer iteration
     unsigned long long cyc_refill = 0, cyc_node = 0, cyc_tri = 0, t_mark = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    // launch timeline (PRT_TIMELINE_WORDS): s_memrealtime is the constant 100 MHz clock all XCDs share (s_memtime, used
+    // for the phase split, counts each XCD's own shader clock)
+    const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long t_exh = 0ull;  // STATS: when this wave found the ray buffer exhausted
+    uint32_t ray_steps = 0u, ray_steps_max = 0u;  // STATS: node steps of the lane's current ray / of its longest ray
     // Exit condition every wave reaches: the loop ends when the ray buffer is exhausted and the wave's lanes are
     // idle; every outer iteration makes progress (a node step, a triangle phase or a refill); the iteration cap is
     // a watchdog that turns a would-be hang into an error flag the host reports.
@@ -1433,6 +1461,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         if (guard > (1u << 22)) {
             if (lane == 0) atomicOr(work + 256, 1u);
             break;
+        }
+        unsigned long long helped = 0ull;  // STEAL: root lanes that have helpers at work (wave-uniform)
+        if (STEAL && exhausted) {
+            for (unsigned long long hm = __ballot(k >= 0xFFFFFF00u && k != 0xFFFFFFFFu); hm; hm &= hm - 1ull)
+                helped |= 1ull << ((uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(hm)) & 63u);
         }
         // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
         if (k != 0xFFFFFFFFu && !pending && tBm == 0u && !(INST && (in_blas || ipm != 0u))) {
@@ -1449,8 +1482,70 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 overflow = false;
                 k = 0xFFFFFFFFu;
             } else if (!(gy > 0x00FFFFFFu) && sp == 0) {
-                hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
-                k = 0xFFFFFFFFu;
+                if (STEAL && k >= 0xFFFFFF00u) {  // a helper (k = 0xFFFFFF00 | root lane): its subtree is done
+                    k = 0xFFFFFFFFu;
+                } else if (!STEAL || ((helped >> lane) & 1ull) == 0ull) {
+                    hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
+                    k = 0xFFFFFFFFu;
+                }
+            }
+        }
+        if (STEAL && exhausted && tune.steal != 0u) {  // wave-uniform
+            // a donor gives its bottom stack entry, or, with an empty stack, the far half of its current group's pending children
+            const uint32_t gh = gy >> 24;
+            const bool can_give = k != 0xFFFFFFFFu && (sp > 0 || (gh & (gh - 1u)) != 0u);
+            const unsigned long long free_m = __ballot(k == 0xFFFFFFFFu);
+            const unsigned long long give_m = __ballot(can_give);
+            const uint32_t n_free = (uint32_t)__popcll(free_m), n_give = (uint32_t)__popcll(give_m);
+            if (n_free >= tune.steal && n_give != 0u) {
+                // the queue is empty here (every triangle phase tests all of it): its first words pair thieves and donors
+                const uint32_t n_pair = n_free < n_give ? n_free : n_give;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t give_rank = (uint32_t)__popcll(give_m & below), free_rank = (uint32_t)__popcll(free_m & below);
+                const bool donor = can_give && give_rank < n_pair;
+                const bool thief = k == 0xFFFFFFFFu && free_rank < n_pair;
+                if (donor) {
+                    queue[give_rank] = lane;
+                    if (sp == 0) {  // split the current group: the lowest-priority half of its hits goes through stack row 0
+                        uint32_t far = 0u, rest = gh;
+                        for (uint32_t i = (uint32_t)__popc(gh) >> 1; i != 0u; --i) {
+                            far |= rest & (0u - rest);
+                            rest &= rest - 1u;
+                        }
+                        s_stack[tid] = make_uint2(gx, (far << 24) | (gy & 0x00FFFFFFu));
+                        gy = (rest << 24) | (gy & 0x00FFFFFFu);
+                        sp = 1;  // (taken off again right below)
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const uint32_t src = thief ? ((volatile uint32_t*)queue)[free_rank] : lane;
+                const unsigned long long e64 = ((volatile unsigned long long*)s_stack)[wbase + src];  // the donor's bottom entry
+                const uint2 e = make_uint2((uint32_t)e64, (uint32_t)(e64 >> 32));
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (donor) {
+                    for (int i = 1; i < sp; ++i) s_stack[(i - 1) * 256 + tid] = s_stack[i * 256 + tid];
+                    --sp;
+                }
+                // the ray's constants come out of the donor's registers (every lane takes part in the shuffles)
+                const uint32_t k_src = (uint32_t)__shfl((int)k, (int)src, 64);
+                const float t_ix = __shfl(ix, (int)src, 64), t_iy = __shfl(iy, (int)src, 64), t_iz = __shfl(iz, (int)src, 64);
+                const float t_anx = __shfl(anx, (int)src, 64), t_any = __shfl(any, (int)src, 64), t_anz = __shfl(anz, (int)src, 64);
+                const float t_afx = __shfl(afx, (int)src, 64), t_afy = __shfl(afy, (int)src, 64), t_afz = __shfl(afz, (int)src, 64);
+                const float t_pad = __shfl(pad, (int)src, 64);
+                const uint32_t t_oct = (uint32_t)__shfl((int)octinv4, (int)src, 64);
+                if (thief) {
+                    const uint32_t root = k_src >= 0xFFFFFF00u ? (k_src & 63u) : src;
+                    k = 0xFFFFFF00u | root;
+                    ix = t_ix; iy = t_iy; iz = t_iz;
+                    anx = t_anx; any = t_any; anz = t_anz;
+                    afx = t_afx; afy = t_afy; afz = t_afz;
+                    pad = t_pad;
+                    octinv4 = t_oct;
+                    gx = e.x;
+                    gy = e.y;
+                    sp = 0;
+                    tlimit = limit_from_d2(__uint_as_float((uint32_t)(((volatile unsigned long long*)s_key)[wbase + root] >> 32)), pad);
+                }
             }
         }
         const bool idle = k == 0xFFFFFFFFu;
@@ -1524,15 +1619,21 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             }
         }
         if (!exhausted && (n_idle >= tune.refill_min || (INST && do_sw && n_idle != 0u))) {
-            if (cur == cur_end) {  // grab the next chunk (one global atomic per `chunk` rays)
-                uint32_t c = 0xFFFFFFFFu;
-                if (lane == 0) c = grab_chunk(work, n_chunks, my_xcd, tune.xcd_affinity != 0u);
-                c = (uint32_t)__shfl((int)c, 0, 64);
-                if (c == 0xFFFFFFFFu) {
+            if (cur == cur_end) {  // grab the next chunk / granule
+                uint32_t c = blockIdx.x * 4u + wv;
+                if (!first_grab) {
+                    if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
+                    c = (uint32_t)__shfl((int)c, 0, 64);
+                }
+                first_grab = false;
+                if (c >= n_grabs) {
                     exhausted = true;
+                    if (STATS) t_exh = __builtin_amdgcn_s_memrealtime();
                 } else {
-                    cur = c * chunk;
-                    cur_end = (cur + chunk < count) ? cur + chunk : count;
+                    const uint32_t g0 = c < n_bulk ? c * gran_per_chunk : n_bulk * gran_per_chunk + (c - n_bulk);
+                    const uint32_t g1 = c < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
+                    cur = g0 << 6;
+                    cur_end = (g1 << 6) < count ? (g1 << 6) : count;
                 }
             }
             if (!exhausted) {
@@ -1566,6 +1667,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                             s_slot[tid] = hid;
                         }
                         k = qi;
+                        if (STATS) ray_steps = 0u;
                         gx = 0u;  // the root "group": node 0, one pending hit that decodes to slot 0
                         gy = 1u << (24u + (octinv4 & 7u));
                         sp = 0;
@@ -1623,6 +1725,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
             if (STATS) {
                 ++n_nodes;
+                ++ray_steps;
+                if (ray_steps > ray_steps_max) ray_steps_max = ray_steps;
                 if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[wv];
                 if ((uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
             }
@@ -1690,7 +1794,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 const uint32_t pos = atomicAdd(&s_qn[wv], cnt);
                 if (pos + cnt <= T8_QCAP) {
                     uint32_t qp = pos;
-                    for (uint32_t m = tm; m; m &= m - 1u) queue[qp++] = (lane << 26) | (w1.y + (uint32_t)__builtin_ctz(m));
+                    const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;  // a helper's tests belong to its root
+                    for (uint32_t m = tm; m; m &= m - 1u) queue[qp++] = (own << 26) | (w1.y + (uint32_t)__builtin_ctz(m));
                     pending = true;
                 } else {  // queue full (everything appended later fails as well): wait for the next phase
                     atomicMin(&s_qn[4 + wv], pos);
@@ -1721,7 +1826,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 const uint32_t T = n_fit ? T0 + (uint32_t)__shfl((int)incl, (int)(n_fit - 1u), 64) : T0;
                 if (fits && cntB) {
                     uint32_t qp = T0 + incl - cntB;
-                    for (uint32_t m = tBm; m; m &= m - 1u) queue[qp++] = (lane << 26) | (tBb + (uint32_t)__builtin_ctz(m));
+                    const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;
+                    for (uint32_t m = tBm; m; m &= m - 1u) queue[qp++] = (own << 26) | (tBb + (uint32_t)__builtin_ctz(m));
                     tBm = 0u;
                 }
                 // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
@@ -1783,7 +1889,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = LEAN ? sc.n_prims + win : win;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
-                const unsigned long long won = ((volatile unsigned long long*)s_key)[tid];
+                const unsigned long long won =
+                    ((volatile unsigned long long*)s_key)[(STEAL && k >= 0xFFFFFF00u && k != 0xFFFFFFFFu) ? wbase + (k & 63u) : tid];
                 if (LEAN) {
                     tlimit = limit_from_d2(__uint_as_float((uint32_t)(won >> 32)), pad);  // same value if nothing changed
                 } else if (won != key_best) {
@@ -1807,7 +1914,20 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             atomicAdd(&stats[6], cyc_refill);
             atomicAdd(&stats[7], cyc_node);
             atomicAdd(&stats[8], cyc_tri);
+            unsigned long long* tl = stats + 16 + PRT_TIMELINE_WORDS * tune.probe_slot;
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            if (t_exh == 0ull) t_exh = t_end;
+            if (my_xcd == 0u) {  // the XCDs' clocks are offset against each other: launch-level marks from XCD 0's waves only
+                atomicMin(&tl[0], t_start);
+                atomicMax(&tl[1], t_end);
+                atomicMin(&tl[2], t_exh);
+                atomicMax(&tl[3], t_exh);
+            }
+            atomicAdd(&tl[4], t_end - t_exh);
+            atomicAdd(&tl[5], t_end - t_start);
+            atomicAdd(&tl[6], 1ull);
         }
+        atomicMax(&stats[16 + PRT_TIMELINE_WORDS * tune.probe_slot + 7], (unsigned long long)ray_steps_max);
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
         __syncthreads();
@@ -1891,19 +2011,29 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
     float4 f = valid ? film_local[pl] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float weight = 1.0f;
     const uint32_t lane = lane_id();
-    for (uint32_t s = 0; s < S; ++s) {  // block-uniform trip count
-        uint32_t e = 0xFFFFFFFFu;
-        if (valid) {
-            const float4 r = rad[(size_t)s * tm.n_pix_local + pl];
-            f.x += r.x * weight;
-            f.y += r.y * weight;
-            f.z += r.z * weight;
-            f.w += weight;
-            e = __float_as_uint(r.w);
-        }
-        for (uint32_t dd = 0; dd < max_depth; ++dd) {
-            const unsigned long long mk = __ballot(e == dd);
-            if (mk != 0ull && lane == 0) atomicAdd(&s_ends[dd], (uint32_t)__popcll(mk));
+    // Samples are added in sample order (that fixes the fp32 sum), but their loads do not depend on each other: eight
+    // at a time are in flight (a rank of an 8-GPU run has only four blocks per CU here, too few to hide the latency of
+    // one load per iteration)
+    for (uint32_t s0 = 0; s0 < S; s0 += 8u) {  // block-uniform trip counts
+        float4 r[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j)
+            r[j] = (valid && s0 + j < S) ? rad[(size_t)(s0 + j) * tm.n_pix_local + pl] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            if (s0 + j >= S) break;
+            uint32_t e = 0xFFFFFFFFu;
+            if (valid) {
+                f.x += r[j].x * weight;
+                f.y += r[j].y * weight;
+                f.z += r[j].z * weight;
+                f.w += weight;
+                e = __float_as_uint(r[j].w);
+            }
+            for (uint32_t dd = 0; dd < max_depth; ++dd) {
+                const unsigned long long mk = __ballot(e == dd);
+                if (mk != 0ull && lane == 0) atomicAdd(&s_ends[dd], (uint32_t)__popcll(mk));
+            }
         }
     }
     if (valid && update_film) film_local[pl] = f;
@@ -2127,21 +2257,26 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
         // (deeper host-built trees: rays that need more than 8 entries go through the overflow list to the 4-wide
         // spill-capable instance; C5, 11 levels: deepest stack 8, no such ray)
         const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && (sc.depth8 <= 9u || sc.nodes4 != nullptr));
+        const uint32_t stack_l = tune.stack_lds == 5u ? 11u : lean ? 8u : 15u;
         if (tune.stack_lds == 5u) {
             PRT_LAUNCH_8(11, 5, false);
         } else if (lean) {
             const dim3 grid5(g == tune.grid_blocks ? g + g / 4u : g);  // 5 instead of 4 resident blocks per CU
+            PrtTravTuning t5 = tune;
+            if (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u) t5.steal = 0u;  // (a helper cannot hand a ray to the overflow list)
             if (stats)
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, tune, stats);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats);
             else
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, tune, stats);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats);
         } else {
             PRT_LAUNCH_8(15, 4, false);
         }
 #undef PRT_LAUNCH_8
-        if (sc.nodes4) {  // overflow list -> the spill-capable 4-wide instance
+        // overflow list -> the spill-capable 4-wide instance.  Not launched when the tree is too shallow for any ray to
+        // overflow (C3: 9 levels = 8 stacked groups at most): two tiny launches and their gaps are ~12 us per bounce
+        if (sc.nodes4 && (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u)) {
             hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
             PRT_LAUNCH_T(k_traverse4_persistent, 27, 5, 1, dim3(8), ovf, ovf + 1);
         }

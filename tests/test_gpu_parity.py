@@ -234,7 +234,7 @@ def test_image_parity_mesh_scene_vs_linear_scan_oracle():
     assert r.stats().rays_total == rays
 
 
-@pytest.mark.parametrize("fuse", [0, 1, "exact"])
+@pytest.mark.parametrize("fuse", [0, 1, "exact", "exact-fuse"])
 def test_image_parity_bunny_vs_oracle_bvh(fuse):
     """fuse = 1: the producers shade one analytic-only segment in place (paths advance at different rates).
     "exact": k_shade grids sized from the ray counts the host reads back while the traversal runs (the mode big batches
@@ -244,8 +244,9 @@ def test_image_parity_bunny_vs_oracle_bvh(fuse):
     W, H, spp, depth = 160, 90, 2, 5
     cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
     r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=8, cam=cam)
-    if fuse == "exact":
+    if isinstance(fuse, str):
         r.set_param("exact_grids", 2)
+        r.set_param("fuse", 1 if fuse.endswith("fuse") else 0)
     else:
         r.set_param("fuse", fuse)
     r.ProgressiveRender(spp)

@@ -22,7 +22,7 @@ for world in (1, 2, 4, 8):
     r.Init(film, scene, cam)
     for k, v in params.items():
         r.set_param(k, int(v))
-    sif = min(256, 128 * world)
+    sif = 256  # bench.py's default at 1080p for every N
     r.set_samples_in_flight(sif)
     for _ in range(2):
         r.render_async(256)
@@ -33,5 +33,13 @@ for world in (1, 2, 4, 8):
     r.synchronize()
     dt = (time.perf_counter() - t0) / 4
     base = base or dt
-    print(f"world {world}: rank-0 step {dt * 1e3:.2f} ms  efficiency {base / (dt * world):.3f}  sif {sif} {params}", flush=True)
+    r.enable_timing(True)  # a second, instrumented pass: where the step goes (HIP events around every launch)
+    r.reset_stats()
+    for _ in range(4):
+        r.render_async(256)
+    r.synchronize()
+    st = r.stats()
+    stages = {k: round(getattr(st, k + "_ms") / 4, 2) for k in ("raygen", "intersect", "shade", "accumulate")}
+    print(f"world {world}: rank-0 step {dt * 1e3:.2f} ms  efficiency {base / (dt * world):.3f}  sif {sif} {params} "
+          f"kernels {stages} sum {sum(stages.values()):.2f} ms", flush=True)
     del r
