@@ -196,6 +196,10 @@ def main():
                     "rays_walked_frac": round(rays_walked / max(1, rays_sample), 3),
                     "node_visits_per_walked_ray": round(trav.bvh_node_visits / max(1, rays_walked), 2),
                     "tri_tests_per_walked_ray": round(trav.bvh_tri_tests / max(1, rays_walked), 2),
+                    # divergence (SURVEY 8d's secondary limits): useful lane slots / issued lane slots of the node loop
+                    # and of the cooperative triangle tests, from the instrumented instance on sample 0
+                    "active_lane_frac": {"node_steps": round(trav.bvh_node_visits / max(1, trav.node_lane_slots), 3),
+                                         "triangle_tests": round(trav.bvh_tri_tests / max(1, trav.tri_lane_slots), 3)},
                     "stage_ms": {"raygen": round(st.raygen_ms, 3), "intersect": round(st.intersect_ms, 3),
                                  "shade": round(st.shade_ms, 3), "accumulate": round(st.accumulate_ms, 3)}}
 
