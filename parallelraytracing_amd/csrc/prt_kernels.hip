@@ -1927,13 +1927,24 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             atomicAdd(&tl[5], t_end - t_start);
             atomicAdd(&tl[6], 1ull);
         }
-        atomicMax(&stats[16 + PRT_TIMELINE_WORDS * tune.probe_slot + 7], (unsigned long long)ray_steps_max);
-        atomicAdd(&stats[0], (unsigned long long)n_nodes);
-        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        // one atomic per wave and counter (1.3 M lanes adding to the same words used to take milliseconds)
+        uint32_t w_nodes = n_nodes, w_tris = n_tris, w_steps = ray_steps_max, w_sp = max_sp;
+        for (int off = 32; off > 0; off >>= 1) {
+            w_nodes += (uint32_t)__shfl_xor((int)w_nodes, off, 64);
+            w_tris += (uint32_t)__shfl_xor((int)w_tris, off, 64);
+            const uint32_t a = (uint32_t)__shfl_xor((int)w_steps, off, 64), b = (uint32_t)__shfl_xor((int)w_sp, off, 64);
+            w_steps = a > w_steps ? a : w_steps;
+            w_sp = b > w_sp ? b : w_sp;
+        }
+        if (lane == 0) {
+            atomicMax(&stats[16 + PRT_TIMELINE_WORDS * tune.probe_slot + 7], (unsigned long long)w_steps);
+            atomicAdd(&stats[0], (unsigned long long)w_nodes);
+            atomicAdd(&stats[1], (unsigned long long)w_tris);
+            atomicMax(&stats[5], (unsigned long long)w_sp);
+        }
         __syncthreads();
         if (threadIdx.x < 4) atomicAdd(&stats[3], 64ull * s_iters[threadIdx.x]);
         if (threadIdx.x < 4) atomicAdd(&stats[4], 64ull * s_iters[4 + threadIdx.x]);
-        atomicMax(&stats[5], (unsigned long long)max_sp);
     }
 }
 
