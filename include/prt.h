@@ -286,9 +286,15 @@ int prt_bvh_read4(PrtContext* ctx, float* nodes4);
 int prt_bvh_read8(PrtContext* ctx, uint32_t* nodes8);
 /* Selects the traversal kernel variant (0 = default). For A/B benchmarking only. */
 int prt_set_variant(PrtContext* ctx, int variant);
-/* Tunables (A/B benchmarking): "variant", "grid_blocks", "chunk", "refill_min", "exit_max", "wide" (2 = compressed
- * 8-wide tree, default; 1 = 4-wide; 0 = binary), "stack_lds" (kernel instance), "gpu_build" (1: the next prt_set_scene
- * builds the 8-wide tree on the device: Morton-ordered, faster to build, slower to traverse; world-space meshes only). */
+/* Tunables (A/B benchmarking; defaults = measured best on C3): "variant", "grid_blocks", "chunk", "refill_min",
+ * "exit_max", "tri_min", "wide" (2 = compressed 8-wide tree, default; 1 = 4-wide; 0 = binary), "stack_lds" (kernel
+ * instance), "xcd_affinity" (4-wide / binary kernels), "tail" (64-ray granules per resident wave handed out singly at
+ * the end of the ray buffer), "steal" (idle lanes a draining wave needs before they take over pending subtrees; 0 = off),
+ * "exact_grids" (0/1/2: k_shade grids from the ray counts read back during the traversal: never / big batches / always),
+ * "fuse", "prim_bvh" (0: linear scan over the analytic primitives as in the reference), "measure_spp", "stack_cap"
+ * (test hook), "gpu_build" (1: the next prt_set_scene builds the 8-wide tree on the device: Morton-ordered, faster to
+ * build, slower to traverse; world-space meshes only).  Results never depend on a tunable.  Unknown names / bad values
+ * return PRT_ERR_INVALID. */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */

@@ -132,12 +132,13 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
     # every tunable / kernel instance gives the same hits: the compressed 8-wide tree (default, wide = 2) at both
     # occupancies, the 4-wide tree's instances (wide = 1), the binary tree (wide = 0)
     for wide, name, val in ((2, "stack_lds", 4), (2, "stack_lds", 5), (2, "stack_lds", 6), (2, "chunk", 64), (2, "xcd_affinity", 1), (2, "exit_max", 0), (2, "refill_min", 1),
+                            (2, "steal", 0), (2, "steal", 1), (2, "steal", 64), (2, "tail", 0), (2, "tail", 8),
                             (1, "stack_lds", 0), (1, "stack_lds", 1), (1, "stack_lds", 2), (1, "stack_lds", 3),
                             (1, "stack_lds", 39), (1, "xcd_affinity", 1), (1, "chunk", 64), (0, "stack_lds", 0)):
         r.set_param("wide", wide)
         r.set_param(name, val)
         assert util.hits_equal(r.closest_hit(o, d), want) == [], (wide, name, val)
-        for k_, v_ in (("stack_lds", 0), ("chunk", 256), ("xcd_affinity", 0), ("exit_max", 8), ("refill_min", 32)):
+        for k_, v_ in (("stack_lds", 0), ("chunk", 256), ("xcd_affinity", 0), ("exit_max", 8), ("refill_min", 32), ("steal", 8), ("tail", 1)):
             r.set_param(k_, v_)
     r.set_param("wide", 2)
     st = r.measure_traversal()
@@ -150,6 +151,31 @@ def test_closest_hit_full_size_mesh_vs_oracle_bvh_bit_exact():
         assert util.hits_equal(r.closest_hit(o, d), want) == [], inst
         r.set_param("stack_cap", 0)
     r.set_param("stack_lds", 0)
+
+
+def test_closest_hit_small_launches_subtree_stealing_bit_exact():
+    """Launches of 1 ... 5000 rays spend their whole life in the state the end of a big launch is in: the ray buffer is
+    exhausted at once, waves drain, and idle lanes take over pending subtrees of the remaining rays.  Diffuse
+    bounce rays off the headline mesh (the long ones: up to ~130 node steps), most aggressive stealing (one idle lane is
+    enough), bit-exact against the oracle."""
+    scene, cam, W, H, spp, depth = prt.scenes.config("C3")
+    r, _, _ = make_renderer(scene, 64, 36, cam=prt.Camera(cam.position, width=64, height=36))
+    rng = np.random.default_rng(21)
+    o, d = r.camera_rays(rng.uniform(0, 64, 20000).astype(np.float32), rng.uniform(0, 36, 20000).astype(np.float32))
+    h = r.closest_hit(o, d)
+    on_mesh = h["prim"] >= 2
+    pos, nrm = h["position"][on_mesh], h["normal"][on_mesh]
+    v = rng.normal(size=pos.shape).astype(np.float32)
+    dirs = nrm + v / np.linalg.norm(v, axis=1, keepdims=True)
+    dirs = np.stack([prt.glm_normalize(x) for x in dirs[:5000]])
+    pos = pos[:5000]
+    osc = util.oracle_scene(scene)
+    want = osc.closest_hit(pos, dirs, use_bvh=True, n_threads=8)
+    assert (want["prim"] >= 2).sum() > 300
+    for steal in (1, 8, 0):
+        r.set_param("steal", steal)
+        for n in (1, 63, 64, 65, 257, 1000, 5000):
+            assert util.hits_equal(r.closest_hit(pos[:n], dirs[:n]), want[:n]) == [], (steal, n)
 
 
 def test_scatter_bit_exact_all_materials():
