@@ -104,6 +104,7 @@ struct PrtContext {
     int variant = 0;
     int abvh_enabled = 1;  // prt_set_param("prim_bvh", 0): keep the reference's linear scan over the analytic primitives
     int measure_spp = 1;  // samples of the instrumented batch of prt_measure_traversal
+    int compact_primary = 1;  // prt_set_param("compact_primary", 0): k_raygen stores full ray records (A/B)
     int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
@@ -112,6 +113,8 @@ struct PrtContext {
     uint32_t* h_counts = nullptr;  // pinned: the front / back ray counts of each bounce as the host learns them
     hipEvent_t ev_counts[PRT_MAX_DEPTH + 2] = {};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
+    float4* d_pix = nullptr;      // compact primary rays: one record per local pixel (PrtPrimary)
+    uint32_t pix_entries = 0;
     uint32_t* d_spill = nullptr;  // global part of the per-lane traversal stacks
     size_t spill_entries = 0;
 };
@@ -320,9 +323,21 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     EventPair ep{};
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
+    // compact primary rays (PrtPrimary): the default pipeline without jitter / roulette / clamp / fusion
+    const bool compact = c->compact_primary && !trav_stats && c->variant == 0 && c->dsc.n_nodes != 0u && !c->dsc.abvh_nodes &&
+                         c->sampling.jitter == 0u && c->sampling.rr_depth == 0u && !(c->sampling.clamp > 0.0f) && fuse == 0u &&
+                         prt_traverse_takes_primary(c->dsc, c->tune);
+    if (compact && c->pix_entries < c->tm.n_pix_local) {
+        free_dev(c->d_pix);
+        c->pix_entries = 0;
+        HIPCHECK(c, hipMalloc((void**)&c->d_pix, (size_t)c->tm.n_pix_local * sizeof(float4)));
+        c->pix_entries = c->tm.n_pix_local;
+    }
+    const PrtPrimary primary{(const uint32_t*)c->rb[0].t, c->d_pix, {c->cam.pos.x, c->cam.pos.y, c->cam.pos.z}, c->tm.n_pix_local,
+                             1.0f / (float)c->tm.n_pix_local, first_sample, seed};
     if ((rc = begin_event(c, 0, &ep))) return rc;
     prt_launch_raygen(c->stream, c->dsc, c->cam, c->tm, n_paths, first_sample, seed, c->rb[0], c->d_rad, c->d_counts,
-                      c->d_work, max_depth, c->sampling);
+                      c->d_work, max_depth, c->sampling, compact ? c->d_pix : nullptr);
     if ((rc = end_event(c, &ep))) return rc;
     if (exact) HIPCHECK(c, read_back(0));
     for (uint32_t d = 0; d < max_depth; ++d) {
@@ -335,7 +350,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
                 PrtTravTuning tune = c->tune;
                 tune.probe_slot = d;
                 prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
-                                    c->bvh.max_stack4, tune, trav_stats);
+                                    c->bvh.max_stack4, tune, trav_stats, (compact && d == 0) ? &primary : nullptr);
             }
             else
                 prt_launch_intersect(c->stream, c->dsc, in, front_count, n_paths, stack_depth, c->variant, trav_stats);
@@ -350,7 +365,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         }
         if ((rc = begin_event(c, 2, &ep))) return rc;
         prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling,
-                         n_rays_known);
+                         n_rays_known, (compact && d == 0) ? &primary : nullptr);
         if ((rc = end_event(c, &ep))) return rc;
         if (exact && d + 1 < max_depth) HIPCHECK(c, read_back(d + 1));
     }
@@ -413,6 +428,7 @@ void prt_destroy(PrtContext* c) {
             for (hipEvent_t& e : c->ev_counts) (void)hipEventDestroy(e);
         }
         free_dev(c->d_work);
+        free_dev(c->d_pix);
         free_dev(c->d_spill);
         free_dev(c->d_scratch);
         for (EventPair& ep : c->events) {
@@ -1374,6 +1390,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
     else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
+    else if (n == "compact_primary" && (value == 0 || value == 1)) c->compact_primary = value;
     else if (n == "tail" && value >= 0 && value <= 64) c->tune.tail = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;

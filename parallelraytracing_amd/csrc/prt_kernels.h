@@ -102,22 +102,39 @@ struct PrtRayBuf {
     float* hd2;     // its world distance^2
 };
 
+// Compact primary rays.  Without jitter the primary ray of a path, its RNG seed, throughput (1,1,1) and segment index
+// (0) are functions of the path id alone, so k_raygen stores 12 B per path (path id, the analytic scan's hit id and
+// distance) instead of 56 B plus ONE 16-B record per pixel (direction, pixel index), and the first bounce's traversal
+// and k_shade rebuild the ray from those (C3: 372 M stored primary rays per 256-spp batch = 16 GB less written by
+// k_raygen and 12 GB less read by the first k_shade).  Every primary ray is still traced on its own.  pid aliases the
+// `t` array of the ray buffer (first 4 bytes per slot).
+struct PrtPrimary {
+    const uint32_t* pid;  // path id per ray slot
+    const float4* pix;    // per local pixel: camera-ray direction, pixel index y * W + x (bits)
+    float origin[3];      // camera position
+    uint32_t n_pix_local;
+    float inv_n;          // 1 / n_pix_local (first guess of path id / n_pix_local, corrected exactly)
+    uint32_t first_sample, seed;
+};
+
 #define PRT_CNT_STRIDE 64u  // uint32 per bounce in the counter array: [0] front, [32] back, [16] finished-in-producer counts
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp);
+                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp, float4* compact_pix = nullptr);
 void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                            uint32_t* work, uint32_t max_rays, unsigned long long* stats);
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
-                         const PrtTravTuning& tune, unsigned long long* stats);
+                         const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary = nullptr);
+// true if prt_launch_traverse would run the instance that can rebuild compact primary rays (and needs no overflow list)
+bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune);
 int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes);
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                           uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known);
+                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary = nullptr);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats);
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,

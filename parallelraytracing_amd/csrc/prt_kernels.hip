@@ -102,6 +102,26 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
     return gt < tm.tiles_x * tm.tiles_y && x < tm.W && y < tm.H;
 }
 
+// The primary ray of path i (no jitter: the pixel centre, cpu/renderer.cpp:45) as k_raygen computed it for the path's
+// pixel (PrtPrimary, prt_kernels.h): path id -> (sample, local pixel) -> the pixel's record.
+PRT_DEV void primary_ray(const PrtPrimary& pr, uint32_t i, f3& o, f3& d, uint32_t& pixel, uint32_t& sample) {
+    uint32_t q = (uint32_t)((float)i * pr.inv_n);  // within one of i / n_pix_local
+    uint32_t r = i - q * pr.n_pix_local;
+    if ((int32_t)r < 0) {
+        --q;
+        r += pr.n_pix_local;
+    }
+    if (r >= pr.n_pix_local) {
+        ++q;
+        r -= pr.n_pix_local;
+    }
+    sample = q;
+    const float4 P = pr.pix[r];
+    o = mk3(pr.origin[0], pr.origin[1], pr.origin[2]);
+    d = mk3(P.x, P.y, P.z);
+    pixel = __float_as_uint(P.w);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Ray generation (GenerateCameraRaysKernel, renderer.cu:186-204; pixel centres, cpu/renderer.cpp:45)
 // ---------------------------------------------------------------------------------------------------------
@@ -199,14 +219,14 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 #define RAYGEN_GROUP 8
 // SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
 // which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
-template <bool JITTER, bool SAMPLING, bool ABVH>
+template <bool JITTER, bool SAMPLING, bool ABVH, bool COMPACT = false>
 __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamera cam, PrtTileMap tm, uint32_t S,
                                                             uint32_t first_sample, uint32_t seed,
                                                             float4* __restrict__ ro, float4* __restrict__ rd,
                                                             float4* __restrict__ rt, uint32_t* __restrict__ hit,
                                                             float* __restrict__ hd2, float4* __restrict__ rad,
                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ work,
-                                                            uint32_t max_depth, PrtSampling sp_arg) {
+                                                            uint32_t max_depth, PrtSampling sp_arg, float4* __restrict__ pix) {
     const PrtSampling sp = SAMPLING ? sp_arg : PrtSampling{0u, 0u, 0.0f};
     const uint32_t pl = blockIdx.x * (uint32_t)PRODUCER_BLOCK + threadIdx.x;
     if (blockIdx.y == 0 && pl < 8u) work[32u * pl] = 0u;  // chunk cursors of the traversal kernel that follows
@@ -223,6 +243,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             pixel = py * tm.W + px;
             if (!JITTER) {  // pixel centre, the same ray for every sample (cpu/renderer.cpp:45)
                 camera_ray(cam, (float)px + 0.5f, (float)py + 0.5f, o0, d0);
+                if (COMPACT && blockIdx.y == 0) pix[pl] = make_float4(d0.x, d0.y, d0.z, __uint_as_float(pixel));
                 front0 = classify_ray<ABVH, PRODUCER_BLOCK>(sc, o0, d0, id00, d2_00);
             }
         }
@@ -253,9 +274,13 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 const uint32_t i = sl * tm.n_pix_local + pl;  // path id
                 if (slot0 != 0xFFFFFFFFu) {
                     const uint32_t slot = front ? slot0 + (sl - s0) * stride : slot0 - (sl - s0) * stride;
-                    ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-                    rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
-                    rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                    if (COMPACT) {  // 12 B instead of 56: the consumers of bounce 0 rebuild the rest from the path id (PrtPrimary)
+                        ((uint32_t*)rt)[slot] = i;
+                    } else {
+                        ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+                        rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
+                        rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                    }
                     hit[slot] = id0;
                     hd2[slot] = d2_0;
                 } else {
@@ -416,11 +441,16 @@ __device__ __forceinline__ bool classify_ray(const DevScene& sc, f3 o, f3 d, uin
     id0 = best.id;
     d2_0 = best.d2;
     if (sc.n_nodes == 0u) return false;
-    const f3 ld = normalize3(d);
+    // This box test only decides whether the traversal kernel has to look at the ray at all; it is conservative by the
+    // per-ray pad (2^-18 of the coordinates' magnitude) and by the 1.0000153 factor in limit_from_d2.  The producers'
+    // directions are unit vectors up to rounding (1e-7), and v_rcp_f32 is within 1 ulp (2^-23): both far inside those
+    // margins, so neither the reference's re-normalisation of the direction nor IEEE divisions are spent here (the
+    // producers are VALU-bound: SQ_ACTIVE_INST_VALU x waves per SIMD > 1 for k_shade).
+    const f3 ld = d;
     const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
-    const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
-    const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
-    const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+    const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+    const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+    const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
     const float x0 = __builtin_fmaf(sc.root_min[0], ix, -(o.x + pad) * ix), x1 = __builtin_fmaf(sc.root_max[0], ix, -(o.x - pad) * ix);
     const float y0 = __builtin_fmaf(sc.root_min[1], iy, -(o.y + pad) * iy), y1 = __builtin_fmaf(sc.root_max[1], iy, -(o.y - pad) * iy);
     const float z0 = __builtin_fmaf(sc.root_min[2], iz, -(o.z + pad) * iz), z1 = __builtin_fmaf(sc.root_max[2], iz, -(o.z - pad) * iz);
@@ -1367,7 +1397,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // non-instanced results bit for bit); a candidate's key is its WORLD distance^2 |o - Mat * pos|^2 and its global
 // primitive index, as in the reference.  A lane changes level only when none of its items is left in the queue.
 #define T8_SENTINEL 0xFFFFFFFFu
-template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false>
+template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false, bool PRIM = false>
 __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
@@ -1375,7 +1405,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                                                                     const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ work,
                                                                     uint32_t* __restrict__ ovf, PrtTravTuning tune,
-                                                                    unsigned long long* __restrict__ stats) {
+                                                                    unsigned long long* __restrict__ stats, PrtPrimary pr) {
+    // PRIM: the rays are compact primary rays (PrtPrimary): origin and direction are rebuilt from the path id
     __shared__ uint2 s_stack[(STACK_L + 1) * 256];  // [entry][thread]; one row of slack above the top
     __shared__ unsigned long long s_key[256];       // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
     __shared__ uint32_t s_slot[256];                // per lane: leaf-order slot of that best
@@ -1641,8 +1672,17 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 if (idle && qi < cur_end) {
                     const uint32_t hid = hit[qi];
                     if (hid != HIT_DEAD) {
-                        const float4 O = ro[qi];
-                        const float4 D = rd[qi];
+                        float4 O, D;
+                        if (PRIM) {
+                            f3 po, pd;
+                            uint32_t pixel, sample;
+                            primary_ray(pr, pr.pid[qi], po, pd, pixel, sample);
+                            O = make_float4(po.x, po.y, po.z, 0.f);
+                            D = make_float4(pd.x, pd.y, pd.z, 0.f);
+                        } else {
+                            O = ro[qi];
+                            D = rd[qi];
+                        }
                         o = mk3(O.x, O.y, O.z);
                         ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
                         pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
@@ -1954,7 +1994,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
 // Radiance can only be non-zero at the event that ends a path (emissive materials never scatter,
 // material.h:119-122), so the path carries throughput only and writes rad[path] once, when it ends.
 // ---------------------------------------------------------------------------------------------------------
-template <int FUSE, bool SAMPLING, bool INST, bool ABVH>
+template <int FUSE, bool SAMPLING, bool INST, bool ABVH, bool PRIM = false>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4* __restrict__ ro,
                                                       const float4* __restrict__ rd, const float4* __restrict__ rt,
                                                       const uint32_t* __restrict__ hit, float4* __restrict__ no,
@@ -1962,7 +2002,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
                                                       uint32_t* __restrict__ nhit, float* __restrict__ nhd2,
                                                       float4* __restrict__ rad, uint32_t* __restrict__ counts,
                                                       uint32_t* __restrict__ work, uint32_t iter, uint32_t max_depth,
-                                                      uint32_t cap, PrtSampling sp_arg) {
+                                                      uint32_t cap, PrtSampling sp_arg, PrtPrimary pr) {
+    // PRIM: the first k_shade of a batch whose k_raygen stored compact primary rays (PrtPrimary): ray, RNG seed,
+    // throughput (1,1,1) and segment index (0) follow from the path id
     const PrtSampling sp = SAMPLING ? sp_arg : PrtSampling{0u, 0u, 0.0f};
     const uint32_t nA = CNT_A(counts, iter), nB = CNT_B(counts, iter);
     const uint32_t count = nA + nB;
@@ -1976,17 +2018,26 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     float d2_0 = 3.402823466e+38f;
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
-        const float4 O = ro[src];
-        const float4 D = rd[src];
-        const float4 T = rt[src];
         const uint32_t id = hit[src];
-        pid = __float_as_uint(O.w);
-        rng = __float_as_uint(D.w);
-        depth = __float_as_uint(T.w);  // segment index of this ray (paths advance at different rates, see advance_path)
-        thr = mk3(T.x, T.y, T.z);
-        if (id != HIT_DEAD) {
+        if (PRIM) {
+            pid = pr.pid[src];
+            uint32_t pixel, sample;
+            primary_ray(pr, pid, o, d, pixel, sample);
+            rng = path_seed(pixel, pr.first_sample + sample, pr.seed);
+            depth = 0u;
+            thr = mk3(1.f, 1.f, 1.f);
+        } else {
+            const float4 O = ro[src];
+            const float4 D = rd[src];
+            const float4 T = rt[src];
+            pid = __float_as_uint(O.w);
+            rng = __float_as_uint(D.w);
+            depth = __float_as_uint(T.w);  // segment index of this ray (paths advance at different rates, see advance_path)
+            thr = mk3(T.x, T.y, T.z);
             o = mk3(O.x, O.y, O.z);
             d = mk3(D.x, D.y, D.z);
+        }
+        if (id != HIT_DEAD) {
             const int r = advance_path<1 + FUSE, INST, ABVH, SHADE_BLOCK>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
             front = r == 1;
             back = r == 2;
@@ -2198,17 +2249,20 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + 255u) / 2
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
-                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp) {
+                       uint32_t* work, uint32_t max_depth, const PrtSampling& sp, float4* compact_pix) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
     const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
 #define PRT_RAYGEN(J, SA, AB)                                                                                       \
     hipLaunchKernelGGL((k_raygen<J, SA, AB>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed,  \
-                       out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp)
+                       out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp, nullptr)
     const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
     if (sc.abvh_nodes) {  // many analytic primitives: the general instances with the BVH scan
         if (sp.jitter) PRT_RAYGEN(true, true, true); else PRT_RAYGEN(false, true, true);
     } else if (sp.jitter) {
         if (sa) PRT_RAYGEN(true, true, false); else PRT_RAYGEN(true, false, false);
+    } else if (compact_pix && !sa) {
+        hipLaunchKernelGGL((k_raygen<false, false, false, true>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample,
+                           seed, out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp, compact_pix);
     } else {
         if (sa) PRT_RAYGEN(false, true, false); else PRT_RAYGEN(false, false, false);
     }
@@ -2226,9 +2280,16 @@ __global__ void k_reset_cursors(uint32_t* work) {
     if (threadIdx.x < 8u) work[32u * threadIdx.x] = 0u;
 }
 
+bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune) {
+    // the 5-waves instance of the 8-wide kernel, and a tree shallow enough that no ray can reach the overflow list (its
+    // re-traversal reads full ray records)
+    return sc.nodes8 && !sc.n_insts && (tune.wide == 2u || !sc.nodes4) && (tune.stack_lds == 0u || tune.stack_lds == 6u) &&
+           tune.stack_cap == 0u && sc.depth8 <= 9u;
+}
+
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
-                         const PrtTravTuning& tune, unsigned long long* stats) {
+                         const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary) {
     uint32_t g = tune.grid_blocks;
     const uint32_t need_blocks = blocks_for(max_rays);
     if (g > need_blocks) g = need_blocks;
@@ -2252,10 +2313,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
     do {                                                                                                           \
         if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, true, IN>), grid, block, 0, st, sc, in.o, in.d,       \
-                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats);                                 \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{});                   \
         else                                                                                                       \
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, false, IN>), grid, block, 0, st, sc, in.o, in.d,      \
-                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats);                                 \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{});                   \
     } while (0)
         if (sc.n_insts) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths).
             // 12 stack entries + the lanes' world rays in LDS = the same 40 KB per block as the one-level instance
@@ -2277,10 +2338,13 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             if (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u) t5.steal = 0u;  // (a helper cannot hand a ray to the overflow list)
             if (stats)
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{});
+            else if (primary)  // bounce 0 of a batch whose k_raygen stored compact primary rays
+                hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true, true>), grid5, block, 0, st, sc, in.o, in.d,
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary);
             else
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{});
         } else {
             PRT_LAUNCH_8(15, 4, false);
         }
@@ -2366,15 +2430,18 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
-                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known) {
+                      uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary) {
     // n_rays_known: the ray count of this bounce if the host has it already (0xFFFFFFFF: size the grid for `cap`)
     const uint32_t n_for_grid = n_rays_known == 0xFFFFFFFFu ? cap : (n_rays_known ? n_rays_known : 1u);
     const dim3 grid((uint32_t)((n_for_grid + SHADE_BLOCK - 1) / SHADE_BLOCK));
 #define PRT_SHADE(F, SA, IN, AB)                                                                                    \
     hipLaunchKernelGGL((k_shade<F, SA, IN, AB>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit, out.o, \
-                       out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp)
+                       out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp, PrtPrimary{})
     const bool sa = sp.rr_depth != 0u || sp.clamp > 0.0f;
-    if (sc.abvh_nodes) {  // many analytic primitives: general instances with the BVH scan
+    if (primary) {  // (the host only asks for this with the default instance's conditions: no placed copies, no primitive BVH, no sampling options, no fusion)
+        hipLaunchKernelGGL((k_shade<0, false, false, false, true>), grid, dim3(SHADE_BLOCK), 0, st, sc, in.o, in.d, in.t, in.hit,
+                           out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, depth, max_depth, cap, sp, *primary);
+    } else if (sc.abvh_nodes) {  // many analytic primitives: general instances with the BVH scan
         if (sc.n_insts) PRT_SHADE(0, true, true, true); else PRT_SHADE(0, true, false, true);
     } else if (sc.n_insts) {  // scenes with placed mesh copies: one general instance
         PRT_SHADE(0, true, true, false);
