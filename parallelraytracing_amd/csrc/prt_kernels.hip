@@ -1629,9 +1629,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     gx = 0u;
                     in_blas = false;
                 }
-                ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
-                iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
-                iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                ix = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                iy = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                iz = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
                 const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
                 anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
                 any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
@@ -1686,9 +1686,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         o = mk3(O.x, O.y, O.z);
                         ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
                         pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
-                        ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
-                        iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
-                        iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        ix = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                        iy = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                        iz = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                        // (v_rcp_f32, 1 ulp, instead of IEEE divisions: these reciprocals only feed the box tests, whose
+                        // pad of 2^-18 of the coordinates' magnitude is 32x the 2^-23 that costs; the triangle tests use the
+                        // ray itself)
                         // near planes move out by -pad, far planes by +pad (the near plane is the box's max plane
                         // on an axis the ray travels along negatively):  t = plane * inv - (o +- pad) * inv
                         const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
