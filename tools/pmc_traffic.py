@@ -32,6 +32,16 @@ def instrumented(name):
     return (a[2] if "traverse8" in name else a[-1]) == "true"
 
 
+def family(name):
+    """k_traverse8_persistent<L, W, STATS, INST, LEAN, PRIM>: the PRIM = true instance is the same kernel reading compact
+    primary rays (bounce 0 of a batch); it belongs to the launches bench.py averages over."""
+    if "traverse8" not in name or "<" not in name:
+        return name
+    a = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    a += ["false"] * (5 - len(a))
+    return name[:name.index("<") + 1] + ", ".join(a[:5]) + ">"
+
+
 def total(d, counter):
     """Counter sum and dispatch count of the DOMINANT instance of the kernel (the template instance with the
     largest sum: the overflow-list re-traversal and the instrumented instance are separate, tiny dispatches)."""
@@ -40,6 +50,7 @@ def total(d, counter):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
             if args.kernel in name and r["Counter_Name"] == counter and not instrumented(name):
+                name = family(name)
                 s[name] += float(r["Counter_Value"])
                 n[name].add(r["Dispatch_Id"])
     if not s:
