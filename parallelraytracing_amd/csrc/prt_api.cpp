@@ -330,7 +330,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     if (compact && c->pix_entries < c->tm.n_pix_local) {
         free_dev(c->d_pix);
         c->pix_entries = 0;
-        HIPCHECK(c, hipMalloc((void**)&c->d_pix, (size_t)c->tm.n_pix_local * sizeof(float4)));
+        HIPCHECK(c, hipMalloc((void**)&c->d_pix, 2 * (size_t)c->tm.n_pix_local * sizeof(float4)));
         c->pix_entries = c->tm.n_pix_local;
     }
     const PrtPrimary primary{(const uint32_t*)c->rb[0].t, c->d_pix, {c->cam.pos.x, c->cam.pos.y, c->cam.pos.z}, c->tm.n_pix_local,
@@ -372,7 +372,8 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     // film += the batch's samples (unless this is a measurement run) and per-depth ray counts from the paths' last
     // segment indices
     if ((rc = begin_event(c, 3, &ep))) return rc;
-    prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats);
+    prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats,
+                          compact ? c->d_pix + c->tm.n_pix_local : nullptr);
     if ((rc = end_event(c, &ep))) return rc;
     if (accumulate) c->stats.samples += S_cur;
     HIPCHECK(c, hipGetLastError());

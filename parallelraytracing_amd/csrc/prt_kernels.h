@@ -110,7 +110,8 @@ struct PrtRayBuf {
 // `t` array of the ray buffer (first 4 bytes per slot).
 struct PrtPrimary {
     const uint32_t* pid;  // path id per ray slot
-    const float4* pix;    // per local pixel: camera-ray direction, pixel index y * W + x (bits)
+    const float4* pix;    // per local pixel: camera-ray direction, pixel index y * W + x (bits); then n_pix_local more records:
+                          // what the pixel's paths deliver if they end with their primary ray (read by k_accumulate)
     float origin[3];      // camera position
     uint32_t n_pix_local;
     float inv_n;          // 1 / n_pix_local (first guess of path id / n_pix_local, corrected exactly)
@@ -136,7 +137,8 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
                       uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary = nullptr);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
-                           uint32_t max_depth, bool update_film, unsigned long long* ray_stats);
+                           uint32_t max_depth, bool update_film, unsigned long long* ray_stats,
+                           const float4* pix_end = nullptr);
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,
                         uint32_t H, float* rgb, float* weight);
 void prt_launch_tonemap(hipStream_t st, const float* rgb, const float* weight, uint32_t n_pix, float exposure,

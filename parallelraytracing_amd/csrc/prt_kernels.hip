@@ -283,10 +283,14 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                     }
                     hit[slot] = id0;
                     hd2[slot] = d2_0;
-                } else {
+                } else if (!COMPACT) {
                     rad[i] = L0;  // the path ended with its primary ray (sky / light seen directly), or there is none
                 }
             }
+            // COMPACT: whether the pixel's paths end with their primary ray, and with what, is the same for all its
+            // samples: one record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
+            if (COMPACT && blockIdx.y == 0)
+                pix[tm.n_pix_local + pl] = slot0 != 0xFFFFFFFFu ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
         }
         return;
     }
@@ -2064,7 +2068,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ rad, float4* __restrict__ film_local,
                                                     PrtTileMap tm, uint32_t S, uint32_t max_depth, int update_film,
-                                                    unsigned long long* __restrict__ ray_stats) {
+                                                    unsigned long long* __restrict__ ray_stats,
+                                                    const float4* __restrict__ pix_end) {
+    // pix_end (compact primary rays, optional): per local pixel what its paths deliver if they all ended with their
+    // primary ray (w != 0xFFFFFFFE); those S identical values are not in rad[] and are added from the record.
     // rad[path] = {radiance, index of the path's last segment}.  Ray segments at depth d = paths whose last segment
     // index is >= d: a per-block histogram of the last indices (wave ballots -> LDS) gives the per-depth counts.
     __shared__ uint32_t s_ends[PRT_MAX_DEPTH];
@@ -2074,6 +2081,9 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
     uint32_t x, y;
     const bool valid = pl < tm.n_pix_local && tile_pixel(tm, pl, x, y);
     float4 f = valid ? film_local[pl] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 E = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu));
+    if (valid && pix_end) E = pix_end[pl];
+    const bool ended = __float_as_uint(E.w) != 0xFFFFFFFEu;
     const float weight = 1.0f;
     const uint32_t lane = lane_id();
     // Samples are added in sample order (that fixes the fp32 sum), but their loads do not depend on each other: eight
@@ -2083,7 +2093,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
         float4 r[8];
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j)
-            r[j] = (valid && s0 + j < S) ? rad[(size_t)(s0 + j) * tm.n_pix_local + pl] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[j] = (valid && !ended && s0 + j < S) ? rad[(size_t)(s0 + j) * tm.n_pix_local + pl] : E;
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j) {
             if (s0 + j >= S) break;
@@ -2457,9 +2467,9 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
-                           uint32_t max_depth, bool update_film, unsigned long long* ray_stats) {
+                           uint32_t max_depth, bool update_film, unsigned long long* ray_stats, const float4* pix_end) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(tm.n_pix_local ? tm.n_pix_local : 1)), dim3(256), 0, st, rad,
-                       film_local, tm, S, max_depth, update_film ? 1 : 0, ray_stats);
+                       film_local, tm, S, max_depth, update_film ? 1 : 0, ray_stats, pix_end);
 }
 
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,
