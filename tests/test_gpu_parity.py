@@ -260,11 +260,12 @@ def test_image_parity_mesh_scene_vs_linear_scan_oracle():
     assert r.stats().rays_total == rays
 
 
-@pytest.mark.parametrize("fuse", [0, 1, "exact", "exact-fuse"])
+@pytest.mark.parametrize("fuse", [0, 1, "exact", "exact-fuse", "exact-fullrecords"])
 def test_image_parity_bunny_vs_oracle_bvh(fuse):
     """fuse = 1: the producers shade one analytic-only segment in place (paths advance at different rates).
     "exact": k_shade grids sized from the ray counts the host reads back while the traversal runs (the mode big batches
-    use), including the early stop at the first bounce without rays."""
+    use), including the early stop at the first bounce without rays.  The default pipeline stores compact primary rays
+    (12 B per path + per-pixel records); "fullrecords" switches that off."""
     mesh = prt.scenes.refined("bunny.ply", 30_000)
     scene = prt.scenes.mesh_scene(mesh)
     W, H, spp, depth = 160, 90, 2, 5
@@ -273,6 +274,8 @@ def test_image_parity_bunny_vs_oracle_bvh(fuse):
     if isinstance(fuse, str):
         r.set_param("exact_grids", 2)
         r.set_param("fuse", 1 if fuse.endswith("fuse") else 0)
+        if fuse.endswith("fullrecords"):  # k_raygen stores full 56-B ray records instead of compact primary rays
+            r.set_param("compact_primary", 0)
     else:
         r.set_param("fuse", fuse)
     r.ProgressiveRender(spp)
