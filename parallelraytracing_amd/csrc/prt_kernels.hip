@@ -50,7 +50,7 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // + j * *stride (front) or - j * *stride (back), so that every copy index forms one contiguous, coalesced run.
 template <int BLOCK>
 PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, uint32_t* cntB, uint32_t* cntC,
-                              uint32_t cap, uint32_t mult = 1u, uint32_t* stride = nullptr) {
+                              uint32_t cap, uint32_t mult = 1u, uint32_t* stride = nullptr, uint32_t* base = nullptr) {
     __shared__ uint32_t s_a[BLOCK / 64], s_b[BLOCK / 64], s_c[BLOCK / 64];
     __shared__ uint32_t s_base_a, s_base_b, s_tot_a, s_tot_b;
     const unsigned long long ma = __ballot(front), mb = __ballot(back), mc = __ballot(done);
@@ -81,11 +81,13 @@ PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, 
         for (uint32_t w = 0; w < wave; ++w) j += s_a[w];
         slot = j;
         if (stride) *stride = s_tot_a;
+        if (base) *base = s_base_a;
     } else if (back) {
         uint32_t j = s_base_b + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; ++w) j += s_b[w];
         slot = cap - 1u - j;
         if (stride) *stride = s_tot_b;
+        if (base) *base = s_base_b;
     }
     return slot;
 }
@@ -217,6 +219,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 // computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
 // seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
 #define RAYGEN_GROUP 8
+#define RAYGEN_GROUP_COMPACT 64u  // compact primary rays: one wave's worth of samples per pixel and block
 // SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
 // which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
 template <bool JITTER, bool SAMPLING, bool ABVH, bool COMPACT = false>
@@ -248,8 +251,9 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             }
         }
     }
-    const uint32_t s0 = blockIdx.y * (uint32_t)RAYGEN_GROUP;
-    const uint32_t s1 = (s0 + RAYGEN_GROUP < S) ? s0 + RAYGEN_GROUP : S;
+    const uint32_t group = COMPACT ? RAYGEN_GROUP_COMPACT : RAYGEN_GROUP;
+    const uint32_t s0 = blockIdx.y * group;
+    const uint32_t s1 = (s0 + group < S) ? s0 + group : S;
     if (!JITTER) {
         // Without jitter whether the pixel's primary ray is stored (front / back) or ends right here does not depend
         // on the sample: decide once, reserve the slots of all samples of this group with ONE atomic per side per
@@ -266,31 +270,53 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 back = r == 2;
             }
         }
-        uint32_t stride = 0;
+        uint32_t stride = 0, base = 0;
         const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
-                                                            &CNT_C(counts, 0), n_paths, s1 - s0, &stride);
+                                                            &CNT_C(counts, 0), n_paths, s1 - s0, &stride, &base);
+        if (COMPACT) {
+            // PIXEL-major slots: the (up to 64) samples of a pixel that this block handles sit next to each other, so a
+            // wave of the first bounce's traversal / k_shade works on IDENTICAL rays: no divergence in the node loop, one
+            // cache line per node for the whole wave, one triangle / one material per wave in k_shade.  Each of them is
+            // still traced on its own.  Written wave-transposed (pixel by pixel, one sample per lane): 256-B stores.
+            const uint32_t mult = s1 - s0;
+            const bool stored = slot0 != 0xFFFFFFFFu;
+            // slot of the pixel's first sample: rank among the block's stored pixels x mult, from the block's base
+            uint32_t first = 0u;
+            if (front) first = base + (slot0 - base) * mult;
+            if (back) first = n_paths - 1u - (base + ((n_paths - 1u - slot0) - base) * mult);
+            const uint32_t lane = lane_id();
+            for (unsigned long long m = __ballot(stored); m; m &= m - 1ull) {
+                const int p = __builtin_ctzll(m);
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)first, p);
+                const bool fr = __builtin_amdgcn_readlane((int)front, p) != 0;
+                const uint32_t plp = (uint32_t)__builtin_amdgcn_readlane((int)pl, p);
+                const uint32_t idp = (uint32_t)__builtin_amdgcn_readlane((int)id0, p);
+                const float d2p = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d2_0), p));
+                if (lane < mult) {
+                    const uint32_t slot = fr ? f + lane : f - lane;
+                    ((uint32_t*)rt)[slot] = (s0 + lane) * tm.n_pix_local + plp;  // path id
+                    hit[slot] = idp;
+                    hd2[slot] = d2p;
+                }
+            }
+            if (in_range && blockIdx.y == 0)
+                pix[tm.n_pix_local + pl] = stored ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
+            return;
+        }
         if (in_range) {
             for (uint32_t sl = s0; sl < s1; ++sl) {
                 const uint32_t i = sl * tm.n_pix_local + pl;  // path id
                 if (slot0 != 0xFFFFFFFFu) {
                     const uint32_t slot = front ? slot0 + (sl - s0) * stride : slot0 - (sl - s0) * stride;
-                    if (COMPACT) {  // 12 B instead of 56: the consumers of bounce 0 rebuild the rest from the path id (PrtPrimary)
-                        ((uint32_t*)rt)[slot] = i;
-                    } else {
-                        ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-                        rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
-                        rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
-                    }
+                    ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+                    rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
+                    rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
                     hit[slot] = id0;
                     hd2[slot] = d2_0;
-                } else if (!COMPACT) {
+                } else {
                     rad[i] = L0;  // the path ended with its primary ray (sky / light seen directly), or there is none
                 }
             }
-            // COMPACT: whether the pixel's paths end with their primary ray, and with what, is the same for all its
-            // samples: one record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
-            if (COMPACT && blockIdx.y == 0)
-                pix[tm.n_pix_local + pl] = slot0 != 0xFFFFFFFFu ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
         }
         return;
     }
@@ -2264,7 +2290,9 @@ void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
                        uint32_t* work, uint32_t max_depth, const PrtSampling& sp, float4* compact_pix) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
-    const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + RAYGEN_GROUP - 1) / RAYGEN_GROUP);
+    const bool sa_ = sp.rr_depth != 0u || sp.clamp > 0.0f;
+    const uint32_t group = (compact_pix && !sa_ && !sc.abvh_nodes && !sp.jitter) ? RAYGEN_GROUP_COMPACT : (uint32_t)RAYGEN_GROUP;
+    const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + group - 1) / group);
 #define PRT_RAYGEN(J, SA, AB)                                                                                       \
     hipLaunchKernelGGL((k_raygen<J, SA, AB>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed,  \
                        out.o, out.d, out.t, out.hit, out.hd2, rad, counts, work, max_depth, sp, nullptr)
