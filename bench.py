@@ -121,15 +121,20 @@ def main():
     gather = prt.dist.FilmGather(r, device)
     setup_s = time.time() - t_setup
 
-    # algorithmic traffic of the dominant kernel, measured with the instrumented traversal on sample 0
+    # algorithmic traffic of the dominant kernel, measured with the instrumented traversal on the first samples
+    # (a batch of up to 64 samples, like the timed batches: with compact primary rays a wave of bounce 0 holds 64 samples
+    # of one pixel, which a one-sample batch cannot show in the active-lane fractions; counts are per sample below)
+    n_meas = max(1, min(64, sif))
+    r.set_param("measure_spp", n_meas)
     trav = r.measure_traversal(sample=0)
-    rays_sample = int(trav.rays_total)
-    rays_walked = int(trav.rays_traversed)  # rays that enter the BVH root box; the others never reach this kernel
+    rays_sample = int(trav.rays_total) // n_meas
+    rays_walked = int(trav.rays_traversed) // n_meas  # rays that enter the BVH root box; the others never reach this kernel
     wide8 = int(bvh.n_nodes8) > 0 and args.wide == 2
     node_bytes = NODE_BYTES if wide8 else NODE_BYTES4
     kernel_name = "k_traverse8_persistent" if wide8 else "k_traverse4_persistent"
-    alg_bytes_sample = (node_bytes * int(trav.bvh_node_visits) + TRI_BYTES * int(trav.bvh_tri_tests)
-                        + RAY_FIXED_BYTES * rays_walked)
+    node_visits_sample = int(trav.bvh_node_visits) // n_meas
+    tri_tests_sample = int(trav.bvh_tri_tests) // n_meas
+    alg_bytes_sample = node_bytes * node_visits_sample + TRI_BYTES * tri_tests_sample + RAY_FIXED_BYTES * rays_walked
 
     def step():
         r.render_async(spp_step)
@@ -194,10 +199,10 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
                     "alg_bytes_per_launch": int(bytes_per_launch),
                     "rays_walked_frac": round(rays_walked / max(1, rays_sample), 3),
-                    "node_visits_per_walked_ray": round(trav.bvh_node_visits / max(1, rays_walked), 2),
-                    "tri_tests_per_walked_ray": round(trav.bvh_tri_tests / max(1, rays_walked), 2),
+                    "node_visits_per_walked_ray": round(node_visits_sample / max(1, rays_walked), 2),
+                    "tri_tests_per_walked_ray": round(tri_tests_sample / max(1, rays_walked), 2),
                     # divergence (SURVEY 8d's secondary limits): useful lane slots / issued lane slots of the node loop
-                    # and of the cooperative triangle tests, from the instrumented instance on sample 0
+                    # and of the cooperative triangle tests, from the instrumented instance on a batch of the first (up to 64) samples
                     "active_lane_frac": {"node_steps": round(trav.bvh_node_visits / max(1, trav.node_lane_slots), 3),
                                          "triangle_tests": round(trav.bvh_tri_tests / max(1, trav.tri_lane_slots), 3)},
                     "stage_ms": {"raygen": round(st.raygen_ms, 3), "intersect": round(st.intersect_ms, 3),

@@ -324,7 +324,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
     // compact primary rays (PrtPrimary): the default pipeline without jitter / roulette / clamp / fusion
-    const bool compact = c->compact_primary && !trav_stats && c->variant == 0 && c->dsc.n_nodes != 0u && !c->dsc.abvh_nodes &&
+    const bool compact = c->compact_primary && c->variant == 0 && c->dsc.n_nodes != 0u && !c->dsc.abvh_nodes &&
                          c->sampling.jitter == 0u && c->sampling.rr_depth == 0u && !(c->sampling.clamp > 0.0f) && fuse == 0u &&
                          prt_traverse_takes_primary(c->dsc, c->tune);
     if (compact && c->pix_entries < c->tm.n_pix_local) {

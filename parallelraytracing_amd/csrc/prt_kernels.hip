@@ -2377,7 +2377,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             const dim3 grid5(g == tune.grid_blocks ? g + g / 4u : g);  // 5 instead of 4 resident blocks per CU
             PrtTravTuning t5 = tune;
             if (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u) t5.steal = 0u;  // (a helper cannot hand a ray to the overflow list)
-            if (stats)
+            if (stats && primary)
+                hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true, true>), grid5, block, 0, st, sc, in.o, in.d,
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary);
+            else if (stats)
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true>), grid5, block, 0, st, sc, in.o, in.d,
                                    in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{});
             else if (primary)  // bounce 0 of a batch whose k_raygen stored compact primary rays
