@@ -219,7 +219,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 // computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
 // seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
 #define RAYGEN_GROUP 8
-#define RAYGEN_GROUP_COMPACT 64u  // compact primary rays: one wave's worth of samples per pixel and block
+#define RAYGEN_GROUP_NOJITTER 64u  // without jitter: one wave's worth of samples per pixel and block (pixel-major slots)
 // SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
 // which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
 template <bool JITTER, bool SAMPLING, bool ABVH, bool COMPACT = false>
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             }
         }
     }
-    const uint32_t group = COMPACT ? RAYGEN_GROUP_COMPACT : RAYGEN_GROUP;
+    const uint32_t group = JITTER ? RAYGEN_GROUP : RAYGEN_GROUP_NOJITTER;
     const uint32_t s0 = blockIdx.y * group;
     const uint32_t s1 = (s0 + group < S) ? s0 + group : S;
     if (!JITTER) {
@@ -273,11 +273,12 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         uint32_t stride = 0, base = 0;
         const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
                                                             &CNT_C(counts, 0), n_paths, s1 - s0, &stride, &base);
-        if (COMPACT) {
+        {
             // PIXEL-major slots: the (up to 64) samples of a pixel that this block handles sit next to each other, so a
-            // wave of the first bounce's traversal / k_shade works on IDENTICAL rays: no divergence in the node loop, one
-            // cache line per node for the whole wave, one triangle / one material per wave in k_shade.  Each of them is
-            // still traced on its own.  Written wave-transposed (pixel by pixel, one sample per lane): 256-B stores.
+            // wave of the first bounce's traversal / k_shade works on IDENTICAL rays: no divergence in the node loop (and,
+            // with placed copies, level switches in lockstep), one cache line per node for the whole wave, one triangle /
+            // one material per wave in k_shade.  Each of them is still traced on its own.  Written wave-transposed (pixel
+            // by pixel, one sample per lane): 256-B stores of path ids (COMPACT) or 1-KB stores of full records.
             const uint32_t mult = s1 - s0;
             const bool stored = slot0 != 0xFFFFFFFFu;
             // slot of the pixel's first sample: rank among the block's stored pixels x mult, from the block's base
@@ -292,30 +293,37 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 const uint32_t plp = (uint32_t)__builtin_amdgcn_readlane((int)pl, p);
                 const uint32_t idp = (uint32_t)__builtin_amdgcn_readlane((int)id0, p);
                 const float d2p = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d2_0), p));
+                float4 Op = make_float4(0.f, 0.f, 0.f, 0.f), Dp = Op;
+                uint32_t pixp = 0u;
+                if (!COMPACT) {
+#define PRT_RL(X) __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(X), p))
+                    Op = make_float4(PRT_RL(o.x), PRT_RL(o.y), PRT_RL(o.z), 0.f);
+                    Dp = make_float4(PRT_RL(d.x), PRT_RL(d.y), PRT_RL(d.z), 0.f);
+#undef PRT_RL
+                    pixp = (uint32_t)__builtin_amdgcn_readlane((int)pixel, p);
+                }
                 if (lane < mult) {
                     const uint32_t slot = fr ? f + lane : f - lane;
-                    ((uint32_t*)rt)[slot] = (s0 + lane) * tm.n_pix_local + plp;  // path id
+                    const uint32_t i = (s0 + lane) * tm.n_pix_local + plp;  // path id
+                    if (COMPACT) {  // 12 B per path: bounce 0 rebuilds the rest from the path id (PrtPrimary)
+                        ((uint32_t*)rt)[slot] = i;
+                    } else {
+                        ro[slot] = make_float4(Op.x, Op.y, Op.z, __uint_as_float(i));
+                        rd[slot] = make_float4(Dp.x, Dp.y, Dp.z, __uint_as_float(path_seed(pixp, first_sample + s0 + lane, seed)));
+                        rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                    }
                     hit[slot] = idp;
                     hd2[slot] = d2p;
                 }
             }
-            if (in_range && blockIdx.y == 0)
-                pix[tm.n_pix_local + pl] = stored ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
-            return;
-        }
-        if (in_range) {
-            for (uint32_t sl = s0; sl < s1; ++sl) {
-                const uint32_t i = sl * tm.n_pix_local + pl;  // path id
-                if (slot0 != 0xFFFFFFFFu) {
-                    const uint32_t slot = front ? slot0 + (sl - s0) * stride : slot0 - (sl - s0) * stride;
-                    ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-                    rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
-                    rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
-                    hit[slot] = id0;
-                    hd2[slot] = d2_0;
-                } else {
-                    rad[i] = L0;  // the path ended with its primary ray (sky / light seen directly), or there is none
-                }
+            if (COMPACT) {
+                // whether the pixel's paths end with their primary ray, and with what, is the same for all its samples: one
+                // record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
+                if (in_range && blockIdx.y == 0)
+                    pix[tm.n_pix_local + pl] = stored ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
+            } else if (in_range && !stored) {
+                // the path ended with its primary ray (sky / light seen directly), or there is none
+                for (uint32_t sl = s0; sl < s1; ++sl) rad[sl * tm.n_pix_local + pl] = L0;
             }
         }
         return;
@@ -2290,8 +2298,7 @@ void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
                        uint32_t first_sample, uint32_t seed, const PrtRayBuf& out, float4* rad, uint32_t* counts,
                        uint32_t* work, uint32_t max_depth, const PrtSampling& sp, float4* compact_pix) {
     const uint32_t S = tm.n_pix_local ? n_paths / tm.n_pix_local : 0u;
-    const bool sa_ = sp.rr_depth != 0u || sp.clamp > 0.0f;
-    const uint32_t group = (compact_pix && !sa_ && !sc.abvh_nodes && !sp.jitter) ? RAYGEN_GROUP_COMPACT : (uint32_t)RAYGEN_GROUP;
+    const uint32_t group = sp.jitter ? (uint32_t)RAYGEN_GROUP : RAYGEN_GROUP_NOJITTER;
     const dim3 grid((tm.n_pix_local + PRODUCER_BLOCK - 1) / PRODUCER_BLOCK, (S + group - 1) / group);
 #define PRT_RAYGEN(J, SA, AB)                                                                                       \
     hipLaunchKernelGGL((k_raygen<J, SA, AB>), grid, dim3(PRODUCER_BLOCK), 0, st, sc, cam, tm, S, first_sample, seed,  \
