@@ -46,8 +46,10 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
 // reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
 // Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
-// `mult` (block-uniform) reserves that many slots per emitting thread: copy j of a thread's ray goes to the returned slot
-// + j * *stride (front) or - j * *stride (back), so that every copy index forms one contiguous, coalesced run.
+// `mult` (block-uniform) reserves that many slots per emitting thread.  With *stride (the block's emitting threads) copy j
+// of a thread's ray can go to the returned slot + j * *stride (front) or - j * *stride (back), so that every copy index
+// forms one contiguous run; with *base (where the block's reservation starts) the caller can instead give each thread
+// `mult` consecutive slots: base + (slot - base) * mult + j (k_raygen's pixel-major order).
 template <int BLOCK>
 PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, uint32_t* cntB, uint32_t* cntC,
                               uint32_t cap, uint32_t mult = 1u, uint32_t* stride = nullptr, uint32_t* base = nullptr) {
@@ -270,9 +272,9 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 back = r == 2;
             }
         }
-        uint32_t stride = 0, base = 0;
+        uint32_t base = 0;
         const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
-                                                            &CNT_C(counts, 0), n_paths, s1 - s0, &stride, &base);
+                                                            &CNT_C(counts, 0), n_paths, s1 - s0, nullptr, &base);
         {
             // PIXEL-major slots: the (up to 64) samples of a pixel that this block handles sit next to each other, so a
             // wave of the first bounce's traversal / k_shade works on IDENTICAL rays: no divergence in the node loop (and,
