@@ -272,10 +272,28 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                 back = r == 2;
             }
         }
-        uint32_t base = 0;
+        uint32_t stride = 0, base = 0;
         const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
-                                                            &CNT_C(counts, 0), n_paths, s1 - s0, nullptr, &base);
-        {
+                                                            &CNT_C(counts, 0), n_paths, s1 - s0, &stride, &base);
+        if (s1 - s0 < 8u) {
+            // few samples per pixel in this batch (interactive use: ProgressiveRender adds ONE sample per call): SAMPLE-major
+            // slots, every thread stores its own pixel's copies, coalesced across the pixels of a wave
+            if (in_range && slot0 != 0xFFFFFFFFu) {
+                for (uint32_t sl = s0; sl < s1; ++sl) {
+                    const uint32_t i = sl * tm.n_pix_local + pl;  // path id
+                    const uint32_t slot = front ? slot0 + (sl - s0) * stride : slot0 - (sl - s0) * stride;
+                    if (COMPACT) {
+                        ((uint32_t*)rt)[slot] = i;
+                    } else {
+                        ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+                        rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
+                        rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                    }
+                    hit[slot] = id0;
+                    hd2[slot] = d2_0;
+                }
+            }
+        } else {
             // PIXEL-major slots: the (up to 64) samples of a pixel that this block handles sit next to each other, so a
             // wave of the first bounce's traversal / k_shade works on IDENTICAL rays: no divergence in the node loop (and,
             // with placed copies, level switches in lockstep), one cache line per node for the whole wave, one triangle /
@@ -318,6 +336,9 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                     hd2[slot] = d2p;
                 }
             }
+        }
+        {
+            const bool stored = slot0 != 0xFFFFFFFFu;
             if (COMPACT) {
                 // whether the pixel's paths end with their primary ray, and with what, is the same for all its samples: one
                 // record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
