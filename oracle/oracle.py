@@ -73,6 +73,14 @@ def lib() -> C.CDLL:
     L.orc_closest_hit.argtypes = [_vp, C.c_uint32, _fp, _fp, C.POINTER(PrtHit), C.c_int, C.c_int]
     L.orc_scatter.restype = C.c_int
     L.orc_scatter.argtypes = [C.POINTER(PrtMaterial), _fp, C.POINTER(PrtHit), _u32p, _fp, _fp, _fp, _fp]
+    L.orc_scatter_batch.restype = None
+    L.orc_scatter_batch.argtypes = [C.POINTER(PrtMaterial), C.c_uint32, _fp, C.POINTER(PrtHit), _u32p, _u32p, _fp, _fp, _fp, _fp]
+    L.orc_fresnel.restype = C.c_float
+    L.orc_fresnel.argtypes = [C.c_float, C.c_float]
+    L.orc_fresnel_libm.restype = C.c_float
+    L.orc_fresnel_libm.argtypes = [C.c_float, C.c_float]
+    L.orc_fresnel_batch.restype = None
+    L.orc_fresnel_batch.argtypes = [C.c_uint32, _fp, _fp, _fp, _fp]
     L.orc_trace.restype = None
     L.orc_trace.argtypes = [_vp, _fp, _fp, C.c_int, _u32p, C.c_int, C.c_int, _fp, _u32p]
     L.orc_render.restype = None
@@ -254,6 +262,32 @@ def scatter(material: PrtMaterial, in_dir, hit_record, rng_state: int):
     sc = lib().orc_scatter(C.byref(material), pd, C.byref(h), C.byref(st), att.ctypes.data_as(_fp),
                            em.ctypes.data_as(_fp), oo.ctypes.data_as(_fp), od.ctypes.data_as(_fp))
     return bool(sc), att, em, oo, od, st.value
+
+
+def scatter_batch(materials, in_dirs, hits: np.ndarray, rng_state):
+    """materials: list of PrtMaterial; hits: HIT_DTYPE array (material_id indexes `materials`).
+    Returns (scattered, attenuation, emitted, out_origin, out_dir, rng_state_after) like HipWavefrontRenderer.scatter."""
+    mats = (PrtMaterial * len(materials))(*materials)
+    d, pd = _f(np.asarray(in_dirs, np.float32).reshape(-1, 3))
+    n = d.shape[0]
+    hits = np.ascontiguousarray(hits)
+    rng = np.ascontiguousarray(rng_state, dtype=np.uint32).copy()
+    sc = np.zeros(n, np.uint32)
+    att, em, oo, od = (np.zeros((n, 3), np.float32) for _ in range(4))
+    lib().orc_scatter_batch(mats, n, pd, hits.ctypes.data_as(C.POINTER(PrtHit)), rng.ctypes.data_as(_u32p),
+                            sc.ctypes.data_as(_u32p), att.ctypes.data_as(_fp), em.ctypes.data_as(_fp),
+                            oo.ctypes.data_as(_fp), od.ctypes.data_as(_fp))
+    return sc.astype(bool), att, em, oo, od, rng
+
+
+def fresnel_batch(cosine, ri):
+    """(contract form, literal libm form) of fresnelReflectance for arrays of inputs."""
+    c, pc = _f(cosine)
+    r, pr = _f(ri)
+    a = np.empty(c.size, np.float32)
+    b = np.empty(c.size, np.float32)
+    lib().orc_fresnel_batch(c.size, pc, pr, a.ctypes.data_as(_fp), b.ctypes.data_as(_fp))
+    return a, b
 
 
 def tonemap(accum, weights, exposure=1.0, gamma=2.2):

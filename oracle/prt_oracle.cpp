@@ -449,8 +449,26 @@ void closest_hit(const OrcScene* s, V3 o, V3 d, int use_bvh, Best* best) {
 }
 
 // fresnelReflectance (material.h:105-109): glm::pow(float,int) is std::pow -> double arithmetic,
-// converted to float by the function's return type.
+// converted to float by the function's return type.  std::pow's last bit is the host libm's business (glibc 2.35 is
+// within 0.52 ulp and differs from the correctly rounded x^5 on 0.09 % of float inputs by one double ulp; MSVC's differs
+// again), so the CONTRACT both this oracle and the HIP path (csrc/prt_device.h, same text) follow is the correctly
+// rounded value: x has <= 24 significant bits, x*x is exact, x^4 = hi + lo exactly, x^5 = hi*x + (err + lo*x) rounded
+// once.  orc_fresnel_libm() keeps the literal std::pow form; tests/test_oracle_kat.py checks that the two agree after the
+// conversion to float on 10^6 inputs (a double ulp survives that conversion with probability ~2^-29).
+inline double pow5_rn(double x) {
+    const double x2 = x * x;
+    const double hi = x2 * x2;
+    const double lo = std::fma(x2, x2, -hi);
+    const double p = hi * x;
+    const double e = std::fma(hi, x, -p);
+    return p + (e + lo * x);
+}
 inline float fresnel_reflectance(float cosine, float ri) {
+    float r0 = (1 - ri) / (1 + ri);
+    r0 = r0 * r0;
+    return (float)((double)r0 + (double)(1 - r0) * pow5_rn((double)(1 - cosine)));
+}
+inline float fresnel_reflectance_libm(float cosine, float ri) {  // material.h:105-109 verbatim, host libm
     float r0 = (1 - ri) / (1 + ri);
     r0 = r0 * r0;
     return (float)((double)r0 + (double)(1 - r0) * std::pow((double)(1 - cosine), 5));
@@ -1044,6 +1062,24 @@ int orc_scatter(const PrtMaterial* m, const float in_dir[3], const PrtHit* hit, 
     st3(out_origin, so);
     st3(out_dir, sd);
     return sc ? 1 : 0;
+}
+
+void orc_scatter_batch(const PrtMaterial* materials, uint32_t n, const float* in_dirs, const PrtHit* hits,
+                       uint32_t* rng_state, uint32_t* scattered, float* attenuation, float* emitted, float* out_origins,
+                       float* out_dirs) {
+    for (uint32_t i = 0; i < n; ++i)
+        scattered[i] = (uint32_t)orc_scatter(&materials[hits[i].material_id], in_dirs + 3 * (size_t)i, &hits[i], &rng_state[i],
+                                             attenuation + 3 * (size_t)i, emitted + 3 * (size_t)i, out_origins + 3 * (size_t)i,
+                                             out_dirs + 3 * (size_t)i);
+}
+
+float orc_fresnel(float cosine, float ri) { return fresnel_reflectance(cosine, ri); }
+float orc_fresnel_libm(float cosine, float ri) { return fresnel_reflectance_libm(cosine, ri); }
+void orc_fresnel_batch(uint32_t n, const float* cosine, const float* ri, float* out, float* out_libm) {
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i] = fresnel_reflectance(cosine[i], ri[i]);
+        out_libm[i] = fresnel_reflectance_libm(cosine[i], ri[i]);
+    }
 }
 
 void orc_trace(const OrcScene* s, const float o[3], const float d[3], int max_depth, uint32_t* rng_state,

@@ -66,6 +66,17 @@ void orc_closest_hit(const OrcScene* s, uint32_t n, const float* origins, const 
 int orc_scatter(const PrtMaterial* m, const float in_dir[3], const PrtHit* hit, uint32_t* rng_state,
                 float attenuation[3], float emitted[3], float out_origin[3], float out_dir[3]);
 
+/* n hits at once: hit i uses materials[hits[i].material_id] and rng_state[i] (updated in place). */
+void orc_scatter_batch(const PrtMaterial* materials, uint32_t n, const float* in_dirs, const PrtHit* hits,
+                       uint32_t* rng_state, uint32_t* scattered, float* attenuation, float* emitted, float* out_origins,
+                       float* out_dirs);
+
+/* fresnelReflectance (src/core/material.h:105-109).  orc_fresnel: the contract (correctly rounded x^5 in double, the
+ * same text as csrc/prt_device.h); orc_fresnel_libm: the literal std::pow((double)x, 5) of the host's libm. */
+float orc_fresnel(float cosine, float ri);
+float orc_fresnel_libm(float cosine, float ri);
+void orc_fresnel_batch(uint32_t n, const float* cosine, const float* ri, float* out, float* out_libm);
+
 /* CPURenderer::TraceRay (src/backend/cpu/renderer.cpp:59-103) when iterative = 0, or the
  * throughput form TraceRayGPU (src/backend/cuda_megakernel/renderer.cu:81-119) when iterative = 1. */
 void orc_trace(const OrcScene* s, const float o[3], const float d[3], int max_depth, uint32_t* rng_state,

@@ -460,6 +460,10 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     if ((s->n_materials && !s->materials) || (s->n_primitives && !s->primitives) || (s->n_meshes && !s->meshes) ||
         (s->n_instanced_meshes && !s->instanced_meshes) || (s->n_instances && !s->instances))
         return fail(c, PRT_ERR_INVALID, "null array in scene description");
+    // From here on the context's host copies and c->dsc are rewritten in place: a scene the context held before is gone
+    // whatever happens, so every failure below leaves the context WITHOUT a scene (the next render fails with
+    // PRT_ERR_INVALID instead of walking half-built arrays); has_scene is set again only after the last upload.
+    c->has_scene = false;
     // ---- validate + flatten (host) ----
     c->materials.assign(s->materials, s->materials + s->n_materials);
     c->prims.clear();
@@ -875,14 +879,20 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         bi.n_triangles = (uint32_t)slots;
         bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
     }
-    c->has_scene = true;
-    if (!c->has_device) return PRT_OK;  // host-only context: BVH built, nothing to upload
+    if (!c->has_device) {  // host-only context: BVH built, nothing to upload
+        c->has_scene = true;
+        return PRT_OK;
+    }
 
     // ---- upload ----
     HIPCHECK(c, hipSetDevice(c->device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
-    c->has_scene = true;
+    if (gpu_build) {  // the builder's device arrays are the scene's arrays (owned by the context from here on: free_scene)
+        c->d_nodes8 = gb.d_nodes8;
+        c->d_tris = gb.d_tris;
+        c->d_nrms = gb.d_nrms;
+    }
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
@@ -901,11 +911,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     HIPCHECK(c, upload(&c->d_prims, c->prims.data(), c->prims.size() * sizeof(DevPrim)));
     HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
     HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
-    if (gpu_build) {  // the builder's device arrays are the scene's arrays
-        c->d_nodes8 = gb.d_nodes8;
-        c->d_tris = gb.d_tris;
-        c->d_nrms = gb.d_nrms;
-    } else {
+    if (!gpu_build) {
         HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
         HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
     }
@@ -936,7 +942,10 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
     d.tris = (const float4*)c->d_tris;
     d.tri_normals = (const float4*)c->d_nrms;
-    return ensure_counters(c);
+    const int rc_cnt = ensure_counters(c);
+    if (rc_cnt) return rc_cnt;
+    c->has_scene = true;
+    return PRT_OK;
 }
 
 int prt_set_camera(PrtContext* c, const PrtCameraDesc* cam) {

@@ -256,13 +256,26 @@ PRT_DEV void world_hit_from_id(const DevScene& sc, uint32_t id, f3 o, f3 d, Worl
 }
 
 // ---- materials (src/core/material.h) -------------------------------------------------------------------
-// fresnelReflectance (material.h:105-109): std::pow(float,int) promotes to double.
+// fresnelReflectance (material.h:105-109): std::pow(float,int) promotes to double, i.e. the reference evaluates
+// std::pow((double)(1 - cosine), 5.0) with the host's libm.  The oracle calls exactly that (oracle/prt_oracle.cpp);
+// there is no glibc on the device, so this computes the CORRECTLY ROUNDED double x^5 instead: x has at most 24
+// significant bits, so x*x is exact, x^4 = hi + lo exactly (one FMA error term), and x^5 = hi*x + (err + lo*x) is
+// rounded once, off only when the exact value lies within ~2^-100 of a rounding midpoint.  glibc's pow is within
+// 0.52 ulp of the exact value (it rounds correctly except within 0.02 ulp of a midpoint), so the two agree bit for bit
+// except on measure-zero inputs; tests/test_gpu_parity.py::test_dielectric_scatter_sweep_bit_exact checks 10^6 cases.
+// (The previous form x2*x2*x rounded three times and could be a double ulp off.)
+PRT_DEV double pow5_rn(double x) {
+    const double x2 = x * x;                           // exact: 48 significant bits
+    const double hi = x2 * x2;                         // x^4 rounded
+    const double lo = __builtin_fma(x2, x2, -hi);      // x^4 = hi + lo exactly
+    const double p = hi * x;                           // leading part of x^5
+    const double e = __builtin_fma(hi, x, -p);         // hi * x = p + e exactly
+    return p + (e + lo * x);
+}
 PRT_DEV float fresnel_reflectance(float cosine, float ri) {
     float r0 = (1.0f - ri) / (1.0f + ri);
     r0 = r0 * r0;
-    double x = (double)(1.0f - cosine);
-    double x2 = x * x;
-    double x5 = x2 * x2 * x;
+    const double x5 = pow5_rn((double)(1.0f - cosine));
     return (float)((double)r0 + (double)(1.0f - r0) * x5);
 }
 // Reflect(), which is Snell refraction (src/core/math.h:45-50)

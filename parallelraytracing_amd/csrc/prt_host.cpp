@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
+#include <memory>
 #include <queue>
 #include <random>
 #include <sstream>
@@ -382,7 +384,23 @@ double read_bin(const uint8_t*& p, const uint8_t* end, PlyType t, bool& ok) {
 
 }  // namespace
 
+static int load_ply_impl(const char* path, PrtMeshData** out, char* err, size_t err_len);
+
+// No exception crosses the C boundary: an allocation failure on a hostile header (or anything else that throws)
+// becomes PRT_ERR_IO like every other malformed file.
 extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err, size_t err_len) {
+    try {
+        return load_ply_impl(path, out, err, err_len);
+    } catch (const std::exception& e) {
+        if (err && err_len) snprintf(err, err_len, "PLY load failed: %s", e.what());
+        return PRT_ERR_IO;
+    } catch (...) {
+        if (err && err_len) snprintf(err, err_len, "PLY load failed");
+        return PRT_ERR_IO;
+    }
+}
+
+static int load_ply_impl(const char* path, PrtMeshData** out, char* err, size_t err_len) {
     auto fail = [&](const std::string& msg) {
         if (err && err_len) snprintf(err, err_len, "%s", msg.c_str());
         return PRT_ERR_IO;
@@ -423,7 +441,11 @@ extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err,
             have_format = true;
         } else if (tok == "element") {
             PlyElem e;
-            ss >> e.name >> e.count;
+            long long cnt = -1;
+            ss >> e.name >> cnt;
+            // the header's counts are not trusted: every instance of an element takes at least one byte of the body
+            if (ss.fail() || cnt < 0 || (unsigned long long)cnt > buf.size()) return fail("bad element count in: " + line);
+            e.count = (size_t)cnt;
             elems.push_back(e);
         } else if (tok == "property") {
             if (elems.empty()) return fail("property before element");
@@ -450,7 +472,8 @@ extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err,
     }
     if (!ended || !have_format) return fail("truncated PLY header");
 
-    PrtMeshData* m = new PrtMeshData();
+    std::unique_ptr<PrtMeshData> owner(new PrtMeshData());
+    PrtMeshData* m = owner.get();
     const uint8_t* p = buf.data() + pos;
     const uint8_t* end = buf.data() + buf.size();
     // ascii tokenizer
@@ -482,10 +505,7 @@ extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err,
             if (e.props[k].is_list && (n == "vertex_indices" || n == "vertex_index")) ilist = (int)k;
         }
         if (is_vertex) {
-            if (ix < 0 || iy < 0 || iz < 0) {
-                delete m;
-                return fail("vertex element lacks x/y/z");
-            }
+            if (ix < 0 || iy < 0 || iz < 0) return fail("vertex element lacks x/y/z");
             have_normals = inx >= 0 && iny >= 0 && inz >= 0;
             m->pos.resize(3 * e.count);
             if (have_normals) m->nrm.resize(3 * e.count);
@@ -508,6 +528,12 @@ extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err,
                         c = read_bin(p, end, pr.count_type, ok);
                     else
                         ok = next_tok(c);
+                    // a list length is an integer in [0, bytes left] (one byte per entry at least); anything else is a
+                    // malformed body (a negative or non-finite double must not reach the cast)
+                    if (!ok || !(c >= 0.0) || !(c <= (double)(end - p))) {
+                        ok = false;
+                        break;
+                    }
                     const size_t cnt = (size_t)c;
                     const bool keep = is_face && (int)k == ilist;
                     if (keep) poly.clear();
@@ -542,19 +568,13 @@ extern "C" int prt_mesh_load_ply(const char* path, PrtMeshData** out, char* err,
         }
         if (!ok) break;
     }
-    if (!ok) {
-        delete m;
-        return fail("truncated or malformed PLY body");
-    }
+    if (!ok) return fail("truncated or malformed PLY body");
     const size_t nv = m->pos.size() / 3;
     for (uint32_t i : m->idx)
-        if (i >= nv) {
-            delete m;
-            return fail("face index out of range");
-        }
+        if (i >= nv) return fail("face index out of range");
     m->had_normals = have_normals;
     if (!have_normals) compute_normals(m);
-    *out = m;
+    *out = owner.release();
     return PRT_OK;
 }
 

@@ -46,6 +46,9 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
 // reference's warp-aggregated AllocateSlot, renderer.cu:43-67 — costs ~0.9 ms per 8 M rays).
 // Returns the buffer slot for this thread, or 0xFFFFFFFF if it emits nothing.  All threads must call.
+// A kernel that calls this MORE THAN ONCE per block must put a __syncthreads() between two calls: the per-wave counts
+// s_a/s_b/s_c are read by the other waves after the second barrier below, and a wave that ran ahead into the next call
+// would overwrite its own entries under them (k_raygen's jitter loop does; k_shade calls once).
 // `mult` (block-uniform) reserves that many slots per emitting thread.  With *stride (the block's emitting threads) copy j
 // of a thread's ray can go to the returned slot + j * *stride (front) or - j * *stride (back), so that every copy index
 // forms one contiguous run; with *base (where the block's reservation starts) the caller can instead give each thread
@@ -381,6 +384,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             hit[slot] = id0;
             hd2[slot] = d2_0;
         }
+        __syncthreads();  // block_alloc2's LDS counts are reused by the next trip (see its contract)
     }
 }
 

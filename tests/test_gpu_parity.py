@@ -209,6 +209,72 @@ def test_scatter_bit_exact_all_materials():
         assert int(st[i]) == w[5], i
 
 
+def test_dielectric_scatter_sweep_bit_exact():
+    """10^6 dielectric scatter events (DielectricMaterial::Scatter + fresnelReflectance, material.h:76-109): grazing,
+    near-normal and total-internal-reflection cases, both faces, five indices of refraction.  The Schlick term goes
+    through a double pow(x, 5): device and oracle compute the correctly rounded x^5 (csrc/prt_device.h pow5_rn), so a
+    one-ulp disagreement there would flip a reflect / refract decision or an RNG state somewhere in a sweep this size."""
+    scene = prt.Scene(preset=None)
+    for ior in (1.5, 1.33, 2.4, 1.0, 1.05):
+        scene.AddDielectric(ior)
+    scene.AddQuad(1, 1, 0)
+    r, _, _ = make_renderer(scene, 8, 8)
+    rng = np.random.default_rng(17)
+    n = 1_000_000
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    # incoming directions at a chosen angle to the normal: uniform in cos, plus a dense band near grazing / near normal
+    cos_t = np.concatenate([rng.uniform(0, 1, n // 2), rng.uniform(0, 0.02, n // 4), rng.uniform(0.98, 1, n - n // 2 - n // 4)])
+    t = np.cross(nrm, rng.normal(size=(n, 3)))
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    ind = (-cos_t[:, None] * nrm + np.sqrt(1 - cos_t ** 2)[:, None] * t).astype(np.float32)
+    l = np.sqrt((ind.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    ind = (ind / l).astype(np.float32)
+    hits = np.zeros(n, dtype=prt.capi.HIT_DTYPE)
+    hits["front_face"] = rng.integers(0, 2, n)
+    hits["material_id"] = rng.integers(0, 5, n)
+    hits["position"] = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    hits["normal"] = nrm
+    state = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    sc, att, em, oo, od, st = r.scatter(ind, hits, state)
+    wsc, watt, wem, woo, wod, wst = orc.scatter_batch(scene.materials, ind, hits, state)
+    assert np.array_equal(sc, wsc) and np.array_equal(st, wst)
+    assert np.array_equal(att, watt) and np.array_equal(em, wem) and np.array_equal(oo, woo)
+    bad = np.flatnonzero((od != wod).any(axis=1))
+    assert bad.size == 0, (bad[:5], od[bad[:5]], wod[bad[:5]])
+    drew = st != state  # the RNG is drawn only when refraction is possible (short-circuit, material.h:88)
+    assert 0.5 < drew.mean() < 0.99 and sc.all()
+
+
+def test_failed_init_after_a_valid_init_leaves_no_scene():
+    """prt_set_scene rewrites the context in place; when it fails the context must end up WITHOUT a scene (an error on the
+    next render), never with half of the new one (null dereference in k_raygen)."""
+    good = prt.Scene("CORNELL")
+    r, film, cam = make_renderer(good, 32, 32, max_depth=3)
+    r.ProgressiveRender()
+    mesh = prt.Mesh(prt.scenes.asset("icosahedron.ply"))
+    bad = prt.Scene("CORNELL")
+    bad.AddInstance(mesh, 0, scale=(1.0, 3.0, 1.0))  # non-uniform scale: rejected after the host copies were rewritten
+    with pytest.raises(prt.PrtError, match="uniform scale"):
+        r.Init(film, bad, cam)
+    with pytest.raises(prt.PrtError, match="prt_set_scene"):
+        r.ProgressiveRender()
+    with pytest.raises(prt.PrtError, match="prt_set_scene"):
+        r.closest_hit(np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, 1]), (4, 1)))
+    bad2 = prt.Scene("CORNELL")
+    bad2.AddMesh(mesh, 99)  # material out of range
+    with pytest.raises(prt.PrtError):
+        r.Init(film, bad2, cam)
+    with pytest.raises(prt.PrtError, match="prt_set_scene"):
+        r.ProgressiveRender()
+    r.Init(film, good, cam)  # and a valid scene works again on the same context
+    film.Clear()
+    r.ProgressiveRender()
+    r.download()
+    acc, wts, rays = util.oracle_scene(good).render(cam.desc(), 32, 32, spp=1, max_depth=3, seed=0, iterative=True)
+    assert np.array_equal(film.accum, acc)
+
+
 # ---- image level ------------------------------------------------------------------------------------------------------
 IMAGE_CASES = [
     # name, preset, W, H, spp, max_depth, seed

@@ -175,6 +175,32 @@ def test_ply_errors(tmp_path):
         prt.Mesh(str(p))
 
 
+def test_ply_hostile_counts_are_io_errors_not_aborts(tmp_path):
+    """Header counts and list lengths are data from the file: absurd or negative ones must come back as PRT_ERR_IO
+    (no std::bad_alloc / length_error through the C boundary, no undefined double -> size_t cast)."""
+    hdr = "ply\nformat ascii 1.0\nelement vertex {nv}\nproperty float x\nproperty float y\nproperty float z\n" \
+          "element face {nf}\nproperty list uchar int vertex_indices\nend_header\n"
+    p = tmp_path / "hostile.ply"
+    for nv in ("99999999999999999", "-5", "abc", "18446744073709551615"):
+        p.write_text(hdr.format(nv=nv, nf=1) + "0 0 0\n")
+        with pytest.raises(prt.PrtError, match="bad element count"):
+            prt.Mesh(str(p))
+    body = "0 0 0\n1 0 0\n0 1 0\n"
+    for cnt in ("-3", "1e300", "nan", "4000000000"):
+        p.write_text(hdr.format(nv=3, nf=1) + body + f"{cnt} 0 1 2\n")
+        with pytest.raises(prt.PrtError, match="malformed"):
+            prt.Mesh(str(p))
+    # binary: a face list whose count byte promises more entries than the file holds
+    import struct
+    bh = ("ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+          "element face 1\nproperty list uchar int vertex_indices\nend_header\n").encode()
+    p.write_bytes(bh + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + bytes([200]) + struct.pack("<3i", 0, 1, 2))
+    with pytest.raises(prt.PrtError, match="malformed"):
+        prt.Mesh(str(p))
+    p.write_bytes(bh + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + bytes([3]) + struct.pack("<3i", 0, 1, 2))
+    assert prt.Mesh(str(p)).n_triangles == 1
+
+
 # ---- refinement ----------------------------------------------------------------------------------------------------------
 def _edge_counts(idx):
     e = np.concatenate([idx[:, [0, 1]], idx[:, [1, 2]], idx[:, [2, 0]]])

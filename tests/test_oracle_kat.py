@@ -301,6 +301,48 @@ def test_dielectric_refraction_obeys_snell():
         pytest.fail("never refracted")
 
 
+def test_fresnel_contract_equals_libm_pow_after_float_conversion():
+    """fresnelReflectance (material.h:105-109) calls std::pow(double, 5).  The contract form (correctly rounded x^5, the
+    text the HIP path shares) and the literal libm form differ by at most one DOUBLE ulp on ~0.1 % of inputs, which never
+    survives the conversion to float in 10^6 cases; known values: cos = 1 -> r0, cos = 0 -> 1."""
+    rng = np.random.default_rng(3)
+    cosine = np.concatenate([rng.uniform(-1, 1, 700_000), rng.uniform(0.9, 1.0, 300_000)]).astype(np.float32)
+    ri = rng.choice(np.float32([1.5, 1 / 1.5, 1.33, 1 / 1.33, 2.4, 1.0]), cosine.size).astype(np.float32)
+    a, b = orc.fresnel_batch(cosine, ri)
+    assert np.array_equal(a, b)
+    one = np.float32([1.0, 1.0, 0.0])
+    r = np.float32([1.5, 1 / 1.5, 1.5])
+    a, _ = orc.fresnel_batch(one, r)
+    r0 = ((np.float32(1) - r) / (np.float32(1) + r)) ** 2
+    assert np.array_equal(a[:2], r0[:2].astype(np.float32)) and a[2] == 1.0
+    x = np.float32(0.3)  # x^5 = 0.00243 (x is not exactly 0.3: compare in double)
+    got, _ = orc.fresnel_batch(np.float32([1.0]) - x, np.float32([1.0]))  # ri = 1: r0 = 0 -> the result is x^5
+    assert got[0] == np.float32(float(np.float32(1.0) - (np.float32(1.0) - x)) ** 5)
+
+
+def test_scatter_batch_equals_single_calls():
+    rng = np.random.default_rng(8)
+    mats = [_mat(1, (0.5, 0.6, 0.7)), _mat(2, (0.9, 0.8, 0.7), 0.3), _mat(3, s=1.5), _mat(4, (3, 2, 1))]
+    n = 400
+    hits = np.zeros(n, dtype=prt.capi.HIT_DTYPE)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ind = rng.normal(size=(n, 3)).astype(np.float32)
+    ind /= np.linalg.norm(ind, axis=1, keepdims=True)
+    nrm[np.einsum("ij,ij->i", nrm, ind) > 0] *= -1
+    hits["front_face"] = rng.integers(0, 2, n)
+    hits["material_id"] = rng.integers(0, 4, n)
+    hits["position"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    hits["normal"] = nrm
+    state = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    sc, att, em, oo, od, st = orc.scatter_batch(mats, ind, hits, state)
+    for i in range(n):
+        w = orc.scatter(mats[int(hits["material_id"][i])], ind[i], hits[i], int(state[i]))
+        assert bool(sc[i]) == w[0] and int(st[i]) == w[5]
+        assert np.array_equal(att[i], w[1]) and np.array_equal(em[i], w[2])
+        assert np.array_equal(oo[i], w[3]) and np.array_equal(od[i], w[4])
+
+
 def test_emissive_emits_and_never_scatters():
     sc, att, em, oo, od, st = orc.scatter(_mat(4, (10, 5, 5)), (0, -1, 0), _hit(), 3)
     assert not sc and np.array_equal(em, np.float32([10, 5, 5])) and st == 3
