@@ -252,6 +252,10 @@ int prt_film_local(PrtContext* ctx, void** d_ptr, uint64_t* n_floats);
  * d_rgb_sum [H*W*3], d_weight [H*W].  Equivalent of Film::AddSampleBufferGPU's target layout
  * (src/core/film.cu:79-99). */
 int prt_film_resolve(PrtContext* ctx, const void* d_gathered, uint32_t world_size, void* d_rgb_sum, void* d_weight);
+/* The same on a stream of the caller's choice (NULL = the context's stream): the per-frame gather and this un-tiling can
+ * then run on a side stream from a snapshot of the payload while the context's stream already renders the next frame. */
+int prt_film_resolve_on(PrtContext* ctx, void* hip_stream, const void* d_gathered, uint32_t world_size, void* d_rgb_sum,
+                        void* d_weight);
 /* Film::UpdateDisplayGPU (src/core/film.cu:101-132): mean -> Reinhard -> gamma -> RGBA8, from device
  * film buffers to a device RGBA8 buffer [H*W*4]. */
 int prt_film_tonemap(PrtContext* ctx, const void* d_rgb_sum, const void* d_weight, float exposure, float gamma, void* d_rgba8);

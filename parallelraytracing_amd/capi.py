@@ -115,6 +115,7 @@ SIGNATURES = {
     "prt_film_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_film_local": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
     "prt_film_resolve": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp]),
+    "prt_film_resolve_on": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
     "prt_film_tonemap": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
     "prt_film_display": (C.c_int, [_vp, C.c_float, C.c_float, C.POINTER(C.c_uint8)]),
     "prt_camera_rays": (C.c_int, [_vp, C.c_uint32, _fp, _fp, _fp, _fp]),

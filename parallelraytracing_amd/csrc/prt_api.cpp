@@ -1066,15 +1066,20 @@ int prt_film_local(PrtContext* c, void** d_ptr, uint64_t* n_floats) {
     return PRT_OK;
 }
 
-int prt_film_resolve(PrtContext* c, const void* d_gathered, uint32_t world, void* d_rgb, void* d_weight) {
+int prt_film_resolve_on(PrtContext* c, void* hip_stream, const void* d_gathered, uint32_t world, void* d_rgb, void* d_weight) {
     int rc = need_device(c);
     if (rc) return rc;
     if (!c->has_film || !d_gathered || !d_rgb || !d_weight || world != c->tm.world)
         return fail(c, PRT_ERR_INVALID, "bad arguments to prt_film_resolve");
-    prt_launch_resolve(c->stream, (const float4*)d_gathered, world, c->tm.stride, c->tm.W, c->tm.H, (float*)d_rgb,
-                       (float*)d_weight);
+    HIPCHECK(c, hipSetDevice(c->device));
+    prt_launch_resolve(hip_stream ? (hipStream_t)hip_stream : c->stream, (const float4*)d_gathered, world, c->tm.stride, c->tm.W,
+                       c->tm.H, (float*)d_rgb, (float*)d_weight);
     HIPCHECK(c, hipGetLastError());
     return PRT_OK;
+}
+
+int prt_film_resolve(PrtContext* c, const void* d_gathered, uint32_t world, void* d_rgb, void* d_weight) {
+    return prt_film_resolve_on(c, nullptr, d_gathered, world, d_rgb, d_weight);
 }
 
 int prt_film_tonemap(PrtContext* c, const void* d_rgb, const void* d_weight, float exposure, float gamma, void* d_rgba8) {

@@ -389,9 +389,10 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_film_local(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def film_resolve(self, d_gathered: int, d_rgb: int, d_weight: int):
-        self._check(capi.lib().prt_film_resolve(self._ctx, C.c_void_p(d_gathered), self.world_size, C.c_void_p(d_rgb),
-                                                C.c_void_p(d_weight)))
+    def film_resolve(self, d_gathered: int, d_rgb: int, d_weight: int, stream: int = 0):
+        """stream: a raw HIP stream to launch on (0 = the renderer's own stream)."""
+        self._check(capi.lib().prt_film_resolve_on(self._ctx, C.c_void_p(stream), C.c_void_p(d_gathered), self.world_size,
+                                                   C.c_void_p(d_rgb), C.c_void_p(d_weight)))
 
     def film_tonemap(self, d_rgb: int, d_weight: int, d_rgba8: int, exposure: float = 1.0, gamma: float = 2.2):
         self._check(capi.lib().prt_film_tonemap(self._ctx, C.c_void_p(d_rgb), C.c_void_p(d_weight), exposure, gamma,
