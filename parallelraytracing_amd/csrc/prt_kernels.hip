@@ -1845,12 +1845,26 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             const float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);
             const float Bnx = __builtin_fmaf(px, ix, -anx), Bny = __builtin_fmaf(py, iy, -any), Bnz = __builtin_fmaf(pz, iz, -anz);
             const float Bfx = __builtin_fmaf(px, ix, -afx), Bfy = __builtin_fmaf(py, iy, -afy), Bfz = __builtin_fmaf(pz, iz, -afz);
-            const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
             // quantized planes, children 0..3 (a) and 4..7 (b): w2 = {lox a, lox b, loy a, loy b},
-            // w3 = {loz a, loz b, hix a, hix b}, w4 = {hiy a, hiy b, hiz a, hiz b}
-            const uint32_t nxa = nx ? w3.z : w2.x, nxb = nx ? w3.w : w2.y, fxa = nx ? w2.x : w3.z, fxb = nx ? w2.y : w3.w;
-            const uint32_t nya = ny ? w4.x : w2.z, nyb = ny ? w4.y : w2.w, fya = ny ? w2.z : w4.x, fyb = ny ? w2.w : w4.y;
-            const uint32_t nza = nz ? w4.z : w3.x, nzb = nz ? w4.w : w3.y, fza = nz ? w3.x : w4.z, fzb = nz ? w3.y : w4.w;
+            // w3 = {loz a, loz b, hix a, hix b}, w4 = {hiy a, hiy b, hiz a, hiz b}.  The near plane is the hi plane on an
+            // axis the ray travels along negatively.  Selected with v_bfi_b32 under per-axis sign masks, not v_cndmask_b32:
+            // the compiler puts some of these twelve selects on vcc, and a v_cndmask on vcc costs five times a plain
+            // VALU instruction on this chip (tools/issue_rate.hip, profiles/r2_issue_rate.txt)
+            uint32_t mx = (uint32_t)((int32_t)__float_as_uint(ix) >> 31), my = (uint32_t)((int32_t)__float_as_uint(iy) >> 31),
+                     mz = (uint32_t)((int32_t)__float_as_uint(iz) >> 31);
+            asm("" : "+v"(mx), "+v"(my), "+v"(mz));  // (opaque: keeps the and/or form below from being folded back into selects)
+#ifndef PRT_T8_BFI
+#define PRT_T8_BFI 1  // 0: v_cndmask_b32 selects (A/B builds: make EXTRA=-DPRT_T8_BFI=0)
+#endif
+#if PRT_T8_BFI
+#define T8_SEL(M, A, B) (((A) & (M)) | ((B) & ~(M)))
+#else
+#define T8_SEL(M, A, B) ((M) ? (A) : (B))
+#endif
+            const uint32_t nxa = T8_SEL(mx, w3.z, w2.x), nxb = T8_SEL(mx, w3.w, w2.y), fxa = T8_SEL(mx, w2.x, w3.z), fxb = T8_SEL(mx, w2.y, w3.w);
+            const uint32_t nya = T8_SEL(my, w4.x, w2.z), nyb = T8_SEL(my, w4.y, w2.w), fya = T8_SEL(my, w2.z, w4.x), fyb = T8_SEL(my, w2.w, w4.y);
+            const uint32_t nza = T8_SEL(mz, w4.z, w3.x), nzb = T8_SEL(mz, w4.w, w3.y), fza = T8_SEL(mz, w3.x, w4.z), fzb = T8_SEL(mz, w3.y, w4.w);
+#undef T8_SEL
             uint32_t hitmask = 0u;
             // The per-ray pad (2^-18 (|o|_1 + extent) in position space) exceeds the rounding of these plane distances
             // (a few 2^-24 of the same magnitude) by a factor > 10, so no relative slack is needed on top of it.
