@@ -217,11 +217,17 @@ const char* prt_last_error(const PrtContext* ctx);
 int prt_version(void);
 /* Launch on this hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
 int prt_set_stream(PrtContext* ctx, void* hip_stream);
+/* The hipStream_t the context launches on / its device id (-1: host-only context). */
+int prt_get_stream(PrtContext* ctx, void** hip_stream);
+int prt_get_device(const PrtContext* ctx);
 
 /* ---- Renderer::Init / SetCamera (src/core/renderer.h:13-15) ---------------------------------- */
 /* Flattens + uploads the scene and builds the BVH over all mesh triangles.  Replaces
  * BuildWavefrontSceneBuffers (src/backend/cuda_wavefront/soa.cpp:37-114). */
 int prt_set_scene(PrtContext* ctx, const PrtSceneDesc* scene);
+/* Replicates the scene `src` holds (flattened primitives, trees, triangle records) onto dst's device without building
+ * anything again: the scene is read-only and every GPU of a multi-GPU render needs its own copy. */
+int prt_clone_scene(PrtContext* dst, const PrtContext* src);
 int prt_set_camera(PrtContext* ctx, const PrtCameraDesc* cam);
 /* Film::Resize + Clear (src/core/film.cu:11-35) and the image partition of this context:
  * 8x8-pixel tiles, tile t (row-major) belongs to rank t % world_size. */
@@ -300,6 +306,39 @@ int prt_set_variant(PrtContext* ctx, int variant);
  * build, slower to traverse; world-space meshes only).  Results never depend on a tunable.  Unknown names / bad values
  * return PRT_ERR_INVALID. */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
+
+/* ---- several GPUs of one node behind one Renderer (the reference is single-GPU:
+ *      cudaSetDevice(0), src/backend/optix/renderer.cpp:217) ------------------------------------------
+ * A group owns one context per entry of device_ids and drives each from its own host thread.  The image is tiled over
+ * the contexts (prt_set_film(w, h, rank, n): 8x8 tiles dealt round-robin), the scene is built once and cloned, every
+ * rank renders all samples of its tiles (RNG keyed by global pixel and sample: the image does not depend on n), and ONE
+ * gather of the per-tile radiance brings the payloads to rank 0's device, which un-tiles them into the Film layout:
+ *   transport "rccl": ncclSend / ncclRecv inside one group call over xGMI (librccl.so, loaded on demand; needs distinct devices)
+ *   transport "peer": hipMemcpyPeerAsync into rank 0's buffer (also the fallback, and what several ranks on ONE device use)
+ * PRT_GROUP_TRANSPORT=rccl|peer overrides the choice (rccl with a single rank runs a 1-rank ncclAllGather: a hardware
+ * smoke test of the RCCL path).  The same device may appear several times in device_ids (rehearsal / tests on one GPU).
+ * All calls are synchronous and are made from one caller thread. */
+typedef struct PrtGroup PrtGroup;
+int prt_group_create(const int* device_ids, uint32_t n, PrtGroup** out);
+void prt_group_destroy(PrtGroup* g);
+const char* prt_group_last_error(const PrtGroup* g);
+uint32_t prt_group_size(const PrtGroup* g);
+const char* prt_group_transport(const PrtGroup* g);          /* "rccl" | "peer" | "none" (one rank) */
+PrtContext* prt_group_context(PrtGroup* g, uint32_t rank);   /* per-rank tunables / stats; owned by the group */
+int prt_group_set_scene(PrtGroup* g, const PrtSceneDesc* scene);   /* built on rank 0, cloned to the others */
+int prt_group_set_camera(PrtGroup* g, const PrtCameraDesc* cam);
+int prt_group_set_film(PrtGroup* g, uint32_t width, uint32_t height);
+int prt_group_film_clear(PrtGroup* g);
+int prt_group_set_sampling(PrtGroup* g, const PrtSampling* s);
+int prt_group_set_samples_in_flight(PrtGroup* g, uint32_t n);
+int prt_group_set_param(PrtGroup* g, const char* name, int value);
+/* Renderer::ProgressiveRender x spp on every rank's tiles, then the gather + un-tiling on rank 0's device. */
+int prt_group_render(PrtGroup* g, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample);
+/* Whole film (all ranks' tiles) to host / tonemapped to host RGBA8, as prt_film_read / prt_film_display. */
+int prt_group_film_read(PrtGroup* g, float* rgb_sum, float* weight);
+int prt_group_film_display(PrtGroup* g, float exposure, float gamma, uint8_t* rgba8);
+/* Ray counters summed over the ranks; the *_ms fields are the maxima over the ranks. */
+int prt_group_get_stats(PrtGroup* g, PrtStats* out);
 
 /* ---- host-side data formats either side of the path ------------------------------------------- */
 /* PLY ingest with the subset the reference's Mesh asks tinyply for (src/core/mesh.cpp:79-97,113-144):

@@ -8,9 +8,9 @@ from . import capi
 
 capi.lib()  # fail loudly if the HIP extension is missing
 
-from .renderer import (Camera, Film, HipWavefrontRenderer, Mesh, PrtError, Scene, glm_normalize,  # noqa: E402
-                       make_transform, write_pfm, write_ppm)
+from .renderer import (Camera, Film, HipWavefrontGroupRenderer, HipWavefrontRenderer, Mesh, PrtError, Scene,  # noqa: E402
+                       glm_normalize, make_transform, write_pfm, write_ppm)
 from . import dist, scenes  # noqa: E402
 
-__all__ = ["Camera", "Film", "HipWavefrontRenderer", "Mesh", "PrtError", "Scene", "capi", "dist", "glm_normalize",
+__all__ = ["Camera", "Film", "HipWavefrontGroupRenderer", "HipWavefrontRenderer", "Mesh", "PrtError", "Scene", "capi", "dist", "glm_normalize",
            "make_transform", "scenes", "write_pfm", "write_ppm"]

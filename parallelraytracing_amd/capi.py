@@ -104,6 +104,26 @@ SIGNATURES = {
     "prt_last_error": (C.c_char_p, [_vp]),
     "prt_version": (C.c_int, []),
     "prt_set_stream": (C.c_int, [_vp, _vp]),
+    "prt_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "prt_get_device": (C.c_int, [_vp]),
+    "prt_clone_scene": (C.c_int, [_vp, _vp]),
+    "prt_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
+    "prt_group_destroy": (None, [_vp]),
+    "prt_group_last_error": (C.c_char_p, [_vp]),
+    "prt_group_size": (C.c_uint32, [_vp]),
+    "prt_group_transport": (C.c_char_p, [_vp]),
+    "prt_group_context": (_vp, [_vp, C.c_uint32]),
+    "prt_group_set_scene": (C.c_int, [_vp, C.POINTER(PrtSceneDesc)]),
+    "prt_group_set_camera": (C.c_int, [_vp, C.POINTER(PrtCameraDesc)]),
+    "prt_group_set_film": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "prt_group_film_clear": (C.c_int, [_vp]),
+    "prt_group_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),
+    "prt_group_set_samples_in_flight": (C.c_int, [_vp, C.c_uint32]),
+    "prt_group_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "prt_group_render": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "prt_group_film_read": (C.c_int, [_vp, _fp, _fp]),
+    "prt_group_film_display": (C.c_int, [_vp, C.c_float, C.c_float, C.POINTER(C.c_uint8)]),
+    "prt_group_get_stats": (C.c_int, [_vp, C.POINTER(PrtStats)]),
     "prt_set_scene": (C.c_int, [_vp, C.POINTER(PrtSceneDesc)]),
     "prt_set_camera": (C.c_int, [_vp, C.POINTER(PrtCameraDesc)]),
     "prt_set_film": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -53,6 +53,7 @@ struct PrtContext {
     std::vector<float> tri_records;   // 12 floats per triangle, leaf order
     std::vector<float> nrm_records;   // 12 floats per triangle, leaf order
     double gpu_build_ms = 0.0;
+    bool scene_device_built = false;  // the scene's 8-wide tree came from the device-side builder (no binary / 4-wide tree)
     std::vector<uint32_t> nodes8_all;  // scenes with placed mesh copies: top-level tree + every mesh's tree
     std::vector<DevInstance> dev_insts;
     std::vector<uint32_t> tlas_inst;   // top-level leaf slot -> instance
@@ -144,6 +145,10 @@ int need_device(PrtContext* c) {
     if (!c->has_device)
         return fail(c, PRT_ERR_NO_DEVICE,
                     "no HIP device bound to this context: the MI355X kernels are the only compute path (no CPU fallback)");
+    // every device entry point starts here: make the context's GPU the calling thread's current device (a process may
+    // hold contexts on several GPUs, each driven from its own host thread: prt_group_*)
+    const hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, PRT_ERR_HIP, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e));
     return PRT_OK;
 }
 
@@ -380,6 +385,74 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     return PRT_OK;
 }
 
+// Second half of prt_set_scene / prt_clone_scene: the context's host copies -> its device.  `gb` (device-side build):
+// the builder's arrays on this device become the scene's arrays; otherwise trees and triangle records are uploaded from
+// the host copies (a scene built on ANOTHER device arrives that way too: its 8-wide tree and records were read back).
+int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    if (gb) {  // owned by the context from here on (free_scene)
+        c->d_nodes8 = gb->d_nodes8;
+        c->d_tris = gb->d_tris;
+        c->d_nrms = gb->d_nrms;
+    }
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    std::vector<float> rgbs(4 * c->materials.size());
+    std::vector<uint32_t> mtype(c->materials.size());
+    for (size_t i = 0; i < c->materials.size(); ++i) {
+        rgbs[4 * i + 0] = c->materials[i].rgb[0];
+        rgbs[4 * i + 1] = c->materials[i].rgb[1];
+        rgbs[4 * i + 2] = c->materials[i].rgb[2];
+        rgbs[4 * i + 3] = c->materials[i].scalar;
+        mtype[i] = c->materials[i].type;
+    }
+    HIPCHECK(c, upload(&c->d_prims, c->prims.data(), c->prims.size() * sizeof(DevPrim)));
+    HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
+    HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
+    if (!c->scene_device_built) {  // (device-built scenes have no binary / 4-wide tree: null pointers select the 8-wide kernel)
+        HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
+        HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
+    }
+    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
+    if (!gb && !n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
+    if (!c->abvh.nodes4.empty()) {
+        HIPCHECK(c, upload(&c->d_abvh_nodes, c->abvh.nodes4.data(), c->abvh.nodes4.size() * 4));
+        HIPCHECK(c, upload(&c->d_abvh_order, c->abvh.order.data(), c->abvh.order.size() * 4));
+    }
+    if (!c->dev_insts.empty()) {
+        HIPCHECK(c, upload(&c->d_insts, c->dev_insts.data(), c->dev_insts.size() * sizeof(DevInstance)));
+        HIPCHECK(c, upload(&c->d_tlas_inst, c->tlas_inst.data(), c->tlas_inst.size() * 4));
+    }
+    if (!gb) {
+        HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
+        HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
+    }
+    DevScene& d = c->dsc;
+    d.prims = (const DevPrim*)c->d_prims;
+    d.mat_rgbs = (const float4*)c->d_mat_rgbs;
+    d.mat_type = (const uint32_t*)c->d_mat_type;
+    d.nodes = (const float4*)c->d_nodes;
+    d.nodes4 = (const float4*)c->d_nodes4;
+    d.abvh_nodes = (const float4*)c->d_abvh_nodes;
+    d.abvh_order = (const uint32_t*)c->d_abvh_order;
+    d.depth8 = c->bvh_info.depth8;
+    d.insts = (const DevInstance*)c->d_insts;
+    d.tlas_inst = (const uint32_t*)c->d_tlas_inst;
+    d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
+    d.tris = (const float4*)c->d_tris;
+    d.tri_normals = (const float4*)c->d_nrms;
+    const int rc_cnt = ensure_counters(c);
+    if (rc_cnt) return rc_cnt;
+    c->has_scene = true;
+    return PRT_OK;
+}
+
 int check_ready(PrtContext* c) {
     int rc = need_device(c);
     if (rc) return rc;
@@ -454,6 +527,16 @@ int prt_set_stream(PrtContext* c, void* hip_stream) {
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return PRT_OK;
 }
+
+int prt_get_stream(PrtContext* c, void** hip_stream) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!hip_stream) return PRT_ERR_INVALID;
+    *hip_stream = (void*)c->stream;
+    return PRT_OK;
+}
+
+int prt_get_device(const PrtContext* c) { return c ? c->device : -1; }
 
 int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     if (!c || !s) return PRT_ERR_INVALID;
@@ -879,73 +962,39 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         bi.n_triangles = (uint32_t)slots;
         bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
     }
+    c->scene_device_built = gpu_build;
     if (!c->has_device) {  // host-only context: BVH built, nothing to upload
         c->has_scene = true;
         return PRT_OK;
     }
+    return upload_scene(c, gpu_build ? &gb : nullptr);
+}
 
-    // ---- upload ----
-    HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    free_scene(c);
-    if (gpu_build) {  // the builder's device arrays are the scene's arrays (owned by the context from here on: free_scene)
-        c->d_nodes8 = gb.d_nodes8;
-        c->d_tris = gb.d_tris;
-        c->d_nrms = gb.d_nrms;
+// Replicates the scene of `src` (host copies of the flattened primitives, trees and triangle records) onto the device
+// of `dst` without building anything again: the multi-GPU host path builds the BVH once and clones it N - 1 times.
+int prt_clone_scene(PrtContext* dst, const PrtContext* src) {
+    if (!dst || !src) return PRT_ERR_INVALID;
+    if (!src->has_scene) return fail(dst, PRT_ERR_INVALID, "prt_clone_scene: the source context has no scene");
+    if (dst == src) return PRT_OK;
+    dst->has_scene = false;
+    dst->materials = src->materials;
+    dst->prims = src->prims;
+    dst->bvh = src->bvh;
+    dst->tri_records = src->tri_records;
+    dst->nrm_records = src->nrm_records;
+    dst->gpu_build_ms = src->gpu_build_ms;
+    dst->nodes8_all = src->nodes8_all;
+    dst->dev_insts = src->dev_insts;
+    dst->tlas_inst = src->tlas_inst;
+    dst->abvh = src->abvh;
+    dst->bvh_info = src->bvh_info;
+    dst->dsc = src->dsc;  // scalar fields; every device pointer is replaced by upload_scene
+    dst->scene_device_built = src->scene_device_built;
+    if (!dst->has_device) {
+        dst->has_scene = true;
+        return PRT_OK;
     }
-    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
-        if (e != hipSuccess) return e;
-        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    std::vector<float> rgbs(4 * c->materials.size());
-    std::vector<uint32_t> mtype(c->materials.size());
-    for (size_t i = 0; i < c->materials.size(); ++i) {
-        rgbs[4 * i + 0] = c->materials[i].rgb[0];
-        rgbs[4 * i + 1] = c->materials[i].rgb[1];
-        rgbs[4 * i + 2] = c->materials[i].rgb[2];
-        rgbs[4 * i + 3] = c->materials[i].scalar;
-        mtype[i] = c->materials[i].type;
-    }
-    HIPCHECK(c, upload(&c->d_prims, c->prims.data(), c->prims.size() * sizeof(DevPrim)));
-    HIPCHECK(c, upload(&c->d_mat_rgbs, rgbs.data(), rgbs.size() * 4));
-    HIPCHECK(c, upload(&c->d_mat_type, mtype.data(), mtype.size() * 4));
-    if (!gpu_build) {
-        HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
-        HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
-    }
-    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
-    if (!gpu_build && !n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
-    if (!c->abvh.nodes4.empty()) {
-        HIPCHECK(c, upload(&c->d_abvh_nodes, c->abvh.nodes4.data(), c->abvh.nodes4.size() * 4));
-        HIPCHECK(c, upload(&c->d_abvh_order, c->abvh.order.data(), c->abvh.order.size() * 4));
-    }
-    if (!c->dev_insts.empty()) {
-        HIPCHECK(c, upload(&c->d_insts, c->dev_insts.data(), c->dev_insts.size() * sizeof(DevInstance)));
-        HIPCHECK(c, upload(&c->d_tlas_inst, c->tlas_inst.data(), c->tlas_inst.size() * 4));
-    }
-    if (!gpu_build) {
-        HIPCHECK(c, upload(&c->d_tris, c->tri_records.data(), c->tri_records.size() * 4));
-        HIPCHECK(c, upload(&c->d_nrms, c->nrm_records.data(), c->nrm_records.size() * 4));
-    }
-    d.prims = (const DevPrim*)c->d_prims;
-    d.mat_rgbs = (const float4*)c->d_mat_rgbs;
-    d.mat_type = (const uint32_t*)c->d_mat_type;
-    d.nodes = (const float4*)c->d_nodes;
-    d.nodes4 = (const float4*)c->d_nodes4;
-    d.abvh_nodes = (const float4*)c->d_abvh_nodes;
-    d.abvh_order = (const uint32_t*)c->d_abvh_order;
-    d.depth8 = bi.depth8;
-    d.insts = (const DevInstance*)c->d_insts;
-    d.tlas_inst = (const uint32_t*)c->d_tlas_inst;
-    d.nodes8 = (const uint4*)c->d_nodes8;  // null when the tree has no compressed 8-wide form: the 4-wide kernel runs
-    d.tris = (const float4*)c->d_tris;
-    d.tri_normals = (const float4*)c->d_nrms;
-    const int rc_cnt = ensure_counters(c);
-    if (rc_cnt) return rc_cnt;
-    c->has_scene = true;
-    return PRT_OK;
+    return upload_scene(dst, nullptr);
 }
 
 int prt_set_camera(PrtContext* c, const PrtCameraDesc* cam) {

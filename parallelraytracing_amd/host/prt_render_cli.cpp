@@ -1,7 +1,9 @@
 // prt_render — offline framebuffer dump: the stand-in for the reference's GLFW/ImGui/OpenGL viewer
 // (src/main.cpp:138-170 builds Film/Scene/Camera and Inits the backends; :504-527 is the frame loop).
 //   prt_render [--preset NAME | --ply FILE [--refine N]] [--width W --height H] [--spp N] [--depth D]
-//              [--seed S] [--camera x y z] [--out PREFIX]
+//              [--seed S] [--camera x y z] [--out PREFIX] [--gpus N | --devices a,b,c] [--sif S] [--frames K]
+// --gpus N tiles the image over devices 0..N-1 (--devices: any list; a device may repeat, which rehearses the multi-GPU
+// path on one GPU); the frame is gathered to the first device once per frame (RCCL over xGMI, or peer copies).
 // Writes PREFIX.ppm (tonemapped RGBA8 as PPM) and PREFIX.pfm (mean radiance).
 #include <chrono>
 #include <cstdio>
@@ -22,7 +24,8 @@ static int preset_id(const std::string& n) {
 
 int main(int argc, char** argv) {
     std::string preset = "CORNELL", ply, out = "frame";
-    uint32_t W = 256, H = 256, spp = 1, depth = 2, seed = 0, refine = 0;
+    uint32_t W = 256, H = 256, spp = 1, depth = 2, seed = 0, refine = 0, sif = 0, frames = 1;
+    std::vector<int> devices{0};
     float cam[3] = {5.0f, 5.0f, 8.0f};
     bool cam_set = false;
     for (int i = 1; i < argc; ++i) {
@@ -37,6 +40,10 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = (uint32_t)atoi(next());
         else if (a == "--seed") seed = (uint32_t)atoi(next());
         else if (a == "--out") out = next();
+        else if (a == "--sif") sif = (uint32_t)atoi(next());
+        else if (a == "--frames") frames = (uint32_t)atoi(next());
+        else if (a == "--gpus") { const int n = atoi(next()); devices.clear(); for (int d = 0; d < n; ++d) devices.push_back(d); }
+        else if (a == "--devices") { devices.clear(); std::string l = next(); for (size_t p = 0; p < l.size();) { size_t e = l.find(',', p); if (e == std::string::npos) e = l.size(); devices.push_back(atoi(l.substr(p, e - p).c_str())); p = e + 1; } }
         else if (a == "--camera") { for (int k = 0; k < 3; ++k) cam[k] = (float)atof(next()); cam_set = true; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -62,10 +69,17 @@ int main(int argc, char** argv) {
         camera.width = (float)W;
         camera.height = (float)H;
         prt::Film film(W, H);
-        prt::HipWavefrontRenderer r(0, depth, seed);
+        if (devices.empty()) { fprintf(stderr, "no devices\n"); return 2; }
+        prt::HipWavefrontRenderer r(devices, depth, seed);
         r.Init(film, *scene, camera);
+        if (sif) r.SetSamplesInFlight(sif);
+        if (frames > 1) {  // warm-up frame (first-touch allocations, clocks), then the timed ones
+            r.Render(spp);
+            r.Clear();
+        }
+        const PrtStats st0 = r.Stats();
         const auto t0 = std::chrono::steady_clock::now();
-        r.Render(spp);
+        for (uint32_t f = 0; f < frames; ++f) r.Render(spp);  // each call ends with the gather to the first device
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         r.Download();
         r.UpdateDisplay();
@@ -77,8 +91,10 @@ int main(int argc, char** argv) {
             fprintf(stderr, "cannot write %s.ppm/.pfm\n", out.c_str());
             return 1;
         }
-        printf("%ux%u, %u spp, max_depth %u: %llu rays in %.3f s = %.1f Mrays/s -> %s.ppm, %s.pfm\n", W, H, spp, depth,
-               (unsigned long long)st.rays_total, s, st.rays_total / s / 1e6, out.c_str(), out.c_str());
+        printf("%ux%u, %u spp, max_depth %u, %u GPU(s) [gather: %s]: %llu rays in %.3f s = %.1f Mrays/s -> %s.ppm, %s.pfm\n", W, H,
+               spp * frames, depth, r.DeviceCount(), r.Transport(), (unsigned long long)(st.rays_total - st0.rays_total), s,
+               (st.rays_total - st0.rays_total) / s / 1e6,
+               out.c_str(), out.c_str());
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -121,48 +121,64 @@ public:
     virtual void SetCamera(const Camera& camera) = 0;
 };
 
+// One renderer, one or several GPUs of a node.  devices = {0} is the single-GPU backend; devices = {0, 1, ..., 7} tiles the
+// image over eight GPUs (8x8-pixel tiles dealt round-robin, scene replicated, RNG keyed by global pixel and sample, so the
+// image does not depend on the device count) and gathers the per-tile radiance to devices[0] once per Render call: RCCL
+// (ncclSend / ncclRecv over xGMI) when every rank has its own GPU, peer copies otherwise (include/prt.h, prt_group_*).
 class HipWavefrontRenderer : public Renderer {
 public:
-    explicit HipWavefrontRenderer(int device = 0, uint32_t max_depth = 20 /* src/backend/cpu/renderer.h:34 */, uint32_t seed = 0) : max_depth_(max_depth), seed_(seed) {
-        if (prt_create(device, &ctx_)) {
-            std::string msg = prt_last_error(ctx_);
-            prt_destroy(ctx_);
-            ctx_ = nullptr;
-            throw Error("prt_create: " + msg);
+    explicit HipWavefrontRenderer(int device = 0, uint32_t max_depth = 20 /* src/backend/cpu/renderer.h:34 */, uint32_t seed = 0)
+        : HipWavefrontRenderer(std::vector<int>{device}, max_depth, seed) {}
+    explicit HipWavefrontRenderer(const std::vector<int>& devices, uint32_t max_depth = 20, uint32_t seed = 0) : max_depth_(max_depth), seed_(seed) {
+        if (prt_group_create(devices.data(), (uint32_t)devices.size(), &grp_)) {
+            std::string msg = prt_group_last_error(grp_);
+            prt_group_destroy(grp_);
+            grp_ = nullptr;
+            throw Error("prt_group_create: " + msg);
         }
     }
-    ~HipWavefrontRenderer() override { prt_destroy(ctx_); }
+    ~HipWavefrontRenderer() override { prt_group_destroy(grp_); }
+    HipWavefrontRenderer(const HipWavefrontRenderer&) = delete;
+    HipWavefrontRenderer& operator=(const HipWavefrontRenderer&) = delete;
     void Init(Film& film, const Scene& scene, const Camera& camera) override {
         PrtSceneDesc d = scene.desc();
-        check(prt_set_scene(ctx_, &d));
-        check(prt_set_film(ctx_, film.width, film.height, 0, 1));
+        check(prt_group_set_scene(grp_, &d));  // flattened + BVH built once, cloned to the other GPUs
+        check(prt_group_set_film(grp_, film.width, film.height));
         film_ = &film;
         frame_ = 0;
         SetCamera(camera);
     }
     void SetCamera(const Camera& camera) override {
         PrtCameraDesc d = camera.desc();
-        check(prt_set_camera(ctx_, &d));
+        check(prt_group_set_camera(grp_, &d));
     }
     void ProgressiveRender() override { Render(1); }  // exactly one sample per pixel
     void Render(uint32_t spp) {
-        check(prt_render(ctx_, spp, max_depth_, seed_, frame_));
+        check(prt_group_render(grp_, spp, max_depth_, seed_, frame_));
         frame_ += spp;
     }
-    void Download() { check(prt_film_read(ctx_, film_->accum.data(), film_->weights.data())); }
-    void UpdateDisplay(float exposure = 1.0f, float gamma = 2.2f) { check(prt_film_display(ctx_, exposure, gamma, film_->display.data())); }
+    void SetSamplesInFlight(uint32_t n) { check(prt_group_set_samples_in_flight(grp_, n)); }
+    void SetParam(const char* name, int value) { check(prt_group_set_param(grp_, name, value)); }
+    void Clear() {
+        check(prt_group_film_clear(grp_));
+        frame_ = 0;
+    }
+    void Download() { check(prt_group_film_read(grp_, film_->accum.data(), film_->weights.data())); }
+    void UpdateDisplay(float exposure = 1.0f, float gamma = 2.2f) { check(prt_group_film_display(grp_, exposure, gamma, film_->display.data())); }
     PrtStats Stats() {
         PrtStats s{};
-        check(prt_get_stats(ctx_, &s));
+        check(prt_group_get_stats(grp_, &s));
         return s;
     }
-    PrtContext* context() { return ctx_; }
+    uint32_t DeviceCount() const { return prt_group_size(grp_); }
+    const char* Transport() const { return prt_group_transport(grp_); }
+    PrtContext* context(uint32_t rank = 0) { return prt_group_context(grp_, rank); }
 
 private:
     void check(int rc) {
-        if (rc) throw Error(prt_last_error(ctx_));
+        if (rc) throw Error(prt_group_last_error(grp_));
     }
-    PrtContext* ctx_ = nullptr;
+    PrtGroup* grp_ = nullptr;
     Film* film_ = nullptr;
     uint32_t max_depth_, seed_, frame_ = 0;
 };

@@ -479,6 +479,92 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_set_scene(self._ctx, C.byref(d)))
 
 
+class HipWavefrontGroupRenderer:
+    """Several GPUs of one node behind the Renderer interface: the binding of the C multi-GPU host path
+    (include/prt.h prt_group_*; C++ form: host/prt_renderer.hpp HipWavefrontRenderer(devices)).  One context and one host
+    thread per entry of `devices`, image tiled over them, one gather per ProgressiveRender call to devices[0] (RCCL over
+    xGMI, or peer copies when a device appears more than once).  Everything happens inside libprt.so."""
+
+    def __init__(self, devices, max_depth: int = DEFAULT_MAX_DEPTH, seed: int = 0):
+        self._grp = C.c_void_p()
+        L = capi.lib()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = L.prt_group_create(devs, len(devices), C.byref(self._grp))
+        if rc:
+            msg = L.prt_group_last_error(self._grp).decode()
+            L.prt_group_destroy(self._grp)
+            self._grp = None
+            raise PrtError(f"prt_group_create({list(devices)}) failed: {msg}")
+        self.max_depth = int(max_depth)
+        self.seed = int(seed)
+        self.frame_index = 0
+        self.film: Optional[Film] = None
+
+    def __del__(self):
+        if getattr(self, "_grp", None):
+            capi.lib().prt_group_destroy(self._grp)
+            self._grp = None
+
+    def _check(self, rc: int):
+        if rc:
+            raise PrtError(capi.lib().prt_group_last_error(self._grp).decode())
+
+    @property
+    def transport(self) -> str:
+        return capi.lib().prt_group_transport(self._grp).decode()
+
+    @property
+    def n_devices(self) -> int:
+        return capi.lib().prt_group_size(self._grp)
+
+    def Init(self, film: Film, scene: Scene, camera: Camera):
+        L = capi.lib()
+        d = scene.desc()
+        self._check(L.prt_group_set_scene(self._grp, C.byref(d)))
+        self._check(L.prt_group_set_film(self._grp, film.width, film.height))
+        self.film = film
+        self.frame_index = 0
+        self.SetCamera(camera)
+
+    def SetCamera(self, camera: Camera):
+        d = camera.desc()
+        self._check(capi.lib().prt_group_set_camera(self._grp, C.byref(d)))
+
+    def ProgressiveRender(self, spp: int = 1):
+        self._check(capi.lib().prt_group_render(self._grp, spp, self.max_depth, self.seed, self.frame_index))
+        self.frame_index += spp
+
+    def Clear(self):
+        self._check(capi.lib().prt_group_film_clear(self._grp))
+        self.frame_index = 0
+
+    def set_samples_in_flight(self, n: int):
+        self._check(capi.lib().prt_group_set_samples_in_flight(self._grp, n))
+
+    def set_param(self, name: str, value: int):
+        self._check(capi.lib().prt_group_set_param(self._grp, name.encode(), int(value)))
+
+    def set_sampling(self, jitter: int = 0, rr_depth: int = 0, clamp: float = 0.0) -> PrtSampling:
+        sp = PrtSampling(int(jitter), int(rr_depth), float(clamp))
+        self._check(capi.lib().prt_group_set_sampling(self._grp, C.byref(sp)))
+        return sp
+
+    def download(self) -> Film:
+        f = self.film
+        self._check(capi.lib().prt_group_film_read(self._grp, f.accum.ctypes.data_as(_fp), f.weights.ctypes.data_as(_fp)))
+        return f
+
+    def UpdateDisplay(self, exposure: float = 1.0, gamma: float = 2.2) -> np.ndarray:
+        f = self.film
+        self._check(capi.lib().prt_group_film_display(self._grp, exposure, gamma, f.display.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return f.display
+
+    def stats(self) -> PrtStats:
+        s = PrtStats()
+        self._check(capi.lib().prt_group_get_stats(self._grp, C.byref(s)))
+        return s
+
+
 def write_ppm(path: str, rgba8: np.ndarray):
     a = np.ascontiguousarray(rgba8, dtype=np.uint8)
     if capi.lib().prt_write_ppm(path.encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0]):

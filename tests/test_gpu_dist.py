@@ -57,3 +57,88 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo_matches_one_rank(tmp_path):
     a = np.frombuffer(outs[1][1][-1280 * 720 * 12:], "<f4")
     b = np.frombuffer(outs[2][1][-1280 * 720 * 12:], "<f4")
     assert np.array_equal(a, b)
+
+
+# ---- the C/C++ multi-GPU host path (include/prt.h prt_group_*) ----------------------------------------------------------
+def _frame(renderer_factory, scene, cam, W, H, depth, spp, seed, sampling=None):
+    import numpy as np
+    import parallelraytracing_amd as prt
+    film = prt.Film(W, H)
+    r = renderer_factory()
+    r.max_depth, r.seed = depth, seed
+    r.Init(film, scene, cam)
+    if sampling:
+        r.set_sampling(**sampling)
+    for _ in range(spp):
+        r.ProgressiveRender()  # one sample per call: a gather per call in the group renderer
+    r.download()
+    return r, film, np.array(film.accum), np.array(film.weights)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_group_of_n_contexts_on_one_gpu_equals_one_context(n):
+    """prt_group_*: n contexts (one host thread each) tile the image, the scene is built once and cloned, the payloads are
+    gathered to rank 0 by peer copies and un-tiled: bit-identical to the single-context renderer, and to the oracle; ray
+    counts add up.  (n ranks sharing ONE device is the only multi-rank form a 1-GPU box can run: transport "peer".)"""
+    import numpy as np
+    import parallelraytracing_amd as prt
+    W, H, depth, spp, seed = 203, 117, 6, 3, 5  # not multiples of the 8x8 tile; more tiles than ranks
+    scene = prt.scenes.mesh_scene(prt.scenes.refined("bunny.ply", 20_000))
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    r1, f1, a1, w1 = _frame(lambda: prt.HipWavefrontRenderer(device=0), scene, cam, W, H, depth, spp, seed)
+    rn, fn, an, wn = _frame(lambda: prt.HipWavefrontGroupRenderer([0] * n), scene, cam, W, H, depth, spp, seed)
+    assert rn.transport == "peer" and rn.n_devices == n
+    assert np.array_equal(an, a1) and np.array_equal(wn, w1) and (wn == spp).all()
+    assert rn.stats().rays_total == r1.stats().rays_total
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=seed, iterative=True,
+                                                     use_bvh=True, n_threads=8)
+    assert np.array_equal(an, acc) and rn.stats().rays_total == rays
+    disp = rn.UpdateDisplay()
+    assert np.array_equal(disp, r1.UpdateDisplay())
+    # jittered + roulette, batched: still independent of the rank count
+    rn.Clear()
+    r1.film.Clear()
+    r1.frame_index = 0
+    sp = dict(jitter=1, rr_depth=2, clamp=0.0)
+    rn.set_sampling(**sp)
+    r1.set_sampling(**sp)
+    rn.set_samples_in_flight(4)
+    rn.ProgressiveRender(4)
+    r1.ProgressiveRender(4)
+    assert np.array_equal(rn.download().accum, r1.download().accum)
+
+
+def test_group_single_rank_through_rccl():
+    """PRT_GROUP_TRANSPORT=rccl with one rank: librccl is loaded on demand, ncclCommInitAll builds a 1-rank communicator
+    and the gather runs as ncclAllGather on the context's stream: the RCCL branch of the C host path on real hardware."""
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import parallelraytracing_amd as prt\n"
+        "W, H = 160, 96\n"
+        "scene = prt.Scene('MATERIAL_TEST'); cam = prt.Camera(width=W, height=H)\n"
+        "f1 = prt.Film(W, H); r1 = prt.HipWavefrontRenderer(device=0, max_depth=5, seed=2); r1.Init(f1, scene, cam); r1.ProgressiveRender(3); r1.download()\n"
+        "fg = prt.Film(W, H); rg = prt.HipWavefrontGroupRenderer([0], max_depth=5, seed=2); rg.Init(fg, scene, cam)\n"
+        "assert rg.transport == 'rccl', rg.transport\n"
+        "rg.ProgressiveRender(3); rg.download()\n"
+        "assert np.array_equal(fg.accum, f1.accum) and np.array_equal(fg.weights, f1.weights)\n"
+        "print('GROUP_RCCL_OK')\n" % util.ROOT)
+    env = dict(os.environ, PRT_GROUP_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "GROUP_RCCL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_cpp_cli_tiles_the_frame_over_three_ranks(tmp_path):
+    """The C++ adapter (host/prt_renderer.hpp HipWavefrontRenderer(devices)) through the CLI: --devices 0,0,0 must write
+    the same PFM as --devices 0."""
+    exe = os.path.join(util.ROOT, "parallelraytracing_amd", "csrc", "prt_render")
+    outs = []
+    for devs in ("0", "0,0,0"):
+        out = str(tmp_path / ("f" + str(len(devs))))
+        p = subprocess.run([exe, "--ply", os.path.join(util.ROOT, "assets", "models", "bunny.ply"), "--width", "200", "--height", "120",
+                            "--spp", "3", "--depth", "5", "--seed", "4", "--devices", devs, "--out", out], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append((open(out + ".pfm", "rb").read(), open(out + ".ppm", "rb").read(), p.stdout))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert "1 GPU(s) [gather: none]" in outs[0][2] and "3 GPU(s) [gather: peer]" in outs[1][2]
+    assert outs[0][2].split("rays")[0].split(":")[-1] == outs[1][2].split("rays")[0].split(":")[-1]  # same ray count

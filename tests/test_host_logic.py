@@ -51,6 +51,34 @@ def test_compute_fails_loudly_without_a_device():
         r.stats()
 
 
+def test_group_fails_loudly_without_devices_and_clone_copies_the_host_scene():
+    """The multi-GPU host path (prt_group_*) has no CPU fallback either; prt_clone_scene replicates a built scene (here
+    between two host-only contexts: BVH info and the compressed tree arrive unchanged, nothing is rebuilt)."""
+    import ctypes as C
+    import torch
+    L = prt.capi.lib()
+    if not torch.cuda.is_available():
+        with pytest.raises(prt.PrtError, match="no HIP device"):
+            prt.HipWavefrontGroupRenderer([0, 1])
+    with pytest.raises(prt.PrtError, match="need|device"):
+        prt.HipWavefrontGroupRenderer([-1])
+    with pytest.raises(prt.PrtError, match="1..64"):
+        prt.HipWavefrontGroupRenderer([])
+    a = prt.HipWavefrontRenderer(device=-1)
+    b = prt.HipWavefrontRenderer(device=-1)
+    with pytest.raises(prt.PrtError, match="no scene"):
+        b._check(L.prt_clone_scene(b._ctx, a._ctx))
+    a.set_scene_host_only(prt.scenes.mesh_scene(prt.Mesh(prt.scenes.asset("bunny.ply"))))
+    b._check(L.prt_clone_scene(b._ctx, a._ctx))
+    ia, ib = a.bvh_info(), b.bvh_info()
+    assert (ia.n_nodes8, ia.depth8, ia.n_triangles, ia.n_nodes4) == (ib.n_nodes8, ib.depth8, ib.n_triangles, ib.n_nodes4)
+    assert np.array_equal(a.bvh_read8(), b.bvh_read8())
+    na, ta = a.bvh_read()
+    nb, tb = b.bvh_read()
+    assert np.array_equal(na.view(np.uint32), nb.view(np.uint32)) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))  # (child refs / ids are bit patterns)
+    assert L.prt_get_device(a._ctx) == -1
+
+
 def test_scene_validation_errors():
     r = prt.HipWavefrontRenderer(device=-1)
     bad = prt.Scene(preset=None)
