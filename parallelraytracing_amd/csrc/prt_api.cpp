@@ -453,6 +453,60 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
     return PRT_OK;
 }
 
+// Device-side build (csrc/bvh_gpu.hip) of the 8-wide tree over n triangles given as 9 floats each (+ normals, + a material
+// per triangle): nodes and the triangle / normal records in the tree's slot order come back to the host copies the
+// rest of prt_set_scene works with; with `keep` the device arrays stay allocated and are handed to the caller.
+int device_build(PrtContext* c, const float* verts, const float* norms, const uint32_t* tri_mat, uint32_t n, uint32_t n_prims,
+                 std::vector<uint32_t>& nodes8, uint32_t& depth, float* tri_rec, float* nrm_rec, PrtGpuBvh* keep) {
+    float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t t = 0; t < (size_t)n; ++t)
+        for (int a = 0; a < 3; ++a) {
+            const float* v = &verts[9 * t];
+            const float lo = std::min(v[a], std::min(v[3 + a], v[6 + a])), hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+            const float cc = 0.5f * lo + 0.5f * hi;
+            cmin[a] = std::min(cmin[a], cc);
+            cmax[a] = std::max(cmax[a], cc);
+        }
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    void *dv = nullptr, *dn = nullptr, *dm = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(dv);
+        (void)hipFree(dn);
+        (void)hipFree(dm);
+    };
+    hipError_t e = hipMalloc(&dv, 36 * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&dn, 36 * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&dm, 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(dv, verts, 36 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = norms ? hipMemcpy(dn, norms, 36 * (size_t)n, hipMemcpyHostToDevice) : hipMemset(dn, 0, 36 * (size_t)n);
+    if (e == hipSuccess) e = tri_mat ? hipMemcpy(dm, tri_mat, 4 * (size_t)n, hipMemcpyHostToDevice) : hipMemset(dm, 0, 4 * (size_t)n);
+    if (e != hipSuccess) {
+        drop();
+        return fail(c, PRT_ERR_HIP, "device-side BVH build: %s", hipGetErrorString(e));
+    }
+    PrtGpuBvh gb{};
+    const auto t0 = std::chrono::steady_clock::now();
+    const int brc = prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb);
+    c->gpu_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    drop();
+    if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
+    nodes8.resize(20 * (size_t)gb.n_nodes);
+    depth = gb.depth;
+    e = hipMemcpy(nodes8.data(), gb.d_nodes8, nodes8.size() * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tri_rec, gb.d_tris, 48 * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nrm_rec) e = hipMemcpy(nrm_rec, gb.d_nrms, 48 * (size_t)n, hipMemcpyDeviceToHost);
+    if (keep && e == hipSuccess) {
+        *keep = gb;
+    } else {
+        (void)hipFree(gb.d_nodes8);
+        (void)hipFree(gb.d_tris);
+        (void)hipFree(gb.d_nrms);
+    }
+    if (e != hipSuccess) return fail(c, PRT_ERR_HIP, "device-side BVH build: %s", hipGetErrorString(e));
+    return PRT_OK;
+}
+
 int check_ready(PrtContext* c) {
     int rc = need_device(c);
     if (rc) return rc;
@@ -600,53 +654,27 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     const uint32_t n_prims = (uint32_t)c->prims.size();
     // device-side build (prt_set_param("gpu_build", 1)): Morton-ordered 8-wide tree straight on the GPU (bvh_gpu.hip);
     // only for world-space meshes on a context with a device; anything else takes the host builder below
-    const bool gpu_build = c->gpu_build && c->has_device && n_tris > 0 && s->n_instances == 0;
+    const bool gpu_any = c->gpu_build && c->has_device;  // placed copies and the top-level tree take the device builder too
+    const bool gpu_build = gpu_any && n_tris > 0;
     PrtGpuBvh gb{};
+    c->gpu_build_ms = 0.0;
     const auto t_build0 = std::chrono::steady_clock::now();
     if (gpu_build) {
-        float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (size_t t = 0; t < (size_t)n_tris; ++t)
-            for (int a = 0; a < 3; ++a) {
-                const float* v = &verts[9 * t];
-                const float lo = std::min(v[a], std::min(v[3 + a], v[6 + a])), hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
-                const float cc = 0.5f * lo + 0.5f * hi;
-                cmin[a] = std::min(cmin[a], cc);
-                cmax[a] = std::max(cmax[a], cc);
-            }
-        HIPCHECK(c, hipSetDevice(c->device));
-        HIPCHECK(c, hipStreamSynchronize(c->stream));
-        void *dv = nullptr, *dn = nullptr, *dm = nullptr;
-        HIPCHECK(c, hipMalloc(&dv, verts.size() * 4));
-        HIPCHECK(c, hipMalloc(&dn, norms.size() * 4));
-        HIPCHECK(c, hipMalloc(&dm, tri_mat.size() * 4));
-        HIPCHECK(c, hipMemcpy(dv, verts.data(), verts.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(c, hipMemcpy(dn, norms.data(), norms.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(c, hipMemcpy(dm, tri_mat.data(), tri_mat.size() * 4, hipMemcpyHostToDevice));
-        const auto t_dev0 = std::chrono::steady_clock::now();
-        const int brc = prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, (uint32_t)n_tris,
-                                           n_prims, cmin, cmax, &gb);
-        c->gpu_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count();
-        (void)hipFree(dv);
-        (void)hipFree(dn);
-        (void)hipFree(dm);
-        if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
-        if (gb.depth > 15u) {
-            (void)hipFree(gb.d_nodes8);
-            (void)hipFree(gb.d_tris);
-            (void)hipFree(gb.d_nrms);
-            return fail(c, PRT_ERR_INVALID, "device-built BVH too deep for the traversal stack (%u > 15)", gb.depth);
-        }
-        // host copies for the read-back entry points (prt_bvh_read / prt_bvh_read8); the binary and 4-wide trees of
-        // the A/B kernels are not built in this mode
+        // host copies for the read-back entry points (prt_bvh_read / prt_bvh_read8) and for scenes whose node array is put
+        // together on the host (placed copies); the binary and 4-wide trees of the A/B kernels are not built in this mode
         c->bvh = BvhBuild();
-        c->bvh.nodes8.resize(20 * (size_t)gb.n_nodes);
-        c->bvh.depth8 = gb.depth;
         c->bvh.max_leaf = 3;
         c->tri_records.assign(12 * (size_t)n_tris, 0.0f);
         c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
-        HIPCHECK(c, hipMemcpy(c->bvh.nodes8.data(), gb.d_nodes8, c->bvh.nodes8.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(c, hipMemcpy(c->tri_records.data(), gb.d_tris, c->tri_records.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(c, hipMemcpy(c->nrm_records.data(), gb.d_nrms, c->nrm_records.size() * 4, hipMemcpyDeviceToHost));
+        const int brc = device_build(c, verts.data(), norms.data(), tri_mat.data(), (uint32_t)n_tris, n_prims, c->bvh.nodes8, c->bvh.depth8,
+                                     c->tri_records.data(), c->nrm_records.data(), s->n_instances == 0 ? &gb : nullptr);
+        if (brc) return brc;
+        if (c->bvh.depth8 > 15u) {
+            (void)hipFree(gb.d_nodes8);
+            (void)hipFree(gb.d_tris);
+            (void)hipFree(gb.d_nrms);
+            return fail(c, PRT_ERR_INVALID, "device-built BVH too deep for the traversal stack (%u > 15)", c->bvh.depth8);
+        }
     } else if (!bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh)) {
         return fail(c, PRT_ERR_INVALID, "BVH deeper than the traversal stack (%u > %u)", c->bvh.max_depth, kMaxStack);
     }
@@ -681,13 +709,13 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.n_nodes8 = (uint32_t)(c->bvh.nodes8.size() / 20);
     bi.depth8 = c->bvh.depth8;
     bi.build_ms = (float)(gpu_build ? c->gpu_build_ms : build_ms);
-    bi.built_on_device = gpu_build ? 1u : 0u;
+    bi.built_on_device = (gpu_build || (gpu_any && s->n_instances)) ? 1u : 0u;
     bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
 
     DevScene& d = c->dsc;
     memset(&d, 0, sizeof(d));
     d.n_prims = n_prims;
-    d.n_nodes = gpu_build ? gb.n_nodes : bi.n_nodes;  // "the scene has a BVH" for the producers' classification
+    d.n_nodes = gpu_build ? (uint32_t)(c->bvh.nodes8.size() / 20) : bi.n_nodes;  // "the scene has a BVH" for the producers' classification
     d.n_tris = (uint32_t)n_tris;
     d.pad = kPadCoeff;
     d.extent = extent;
@@ -800,14 +828,20 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
                         B.extent = std::max(B.extent, std::fabs(pv));
                     }
                 }
-            if (!bvh_build(v.data(), me.n_triangles, kMaxLeaf, 0, kMaxStack, &B.bvh) || B.bvh.nodes8.empty())
-                return fail(c, PRT_ERR_INVALID, "instanced mesh %u: BVH construction failed", m);
             B.slot_base = (uint32_t)slots;
             slots += me.n_triangles;
             if (slots >= (1ull << 26)) return fail(c, PRT_ERR_INVALID, "too many triangles (limit 2^26 - 1)");
             // triangle / normal records in this mesh's leaf order: {P0, face index}, {P1, -}, {P2, -}
             c->tri_records.resize(12 * (size_t)slots, 0.0f);
             c->nrm_records.resize(12 * (size_t)slots, 0.0f);
+            if (gpu_any) {  // the mesh's tree in its own space on the device; the records come back in its slot order
+                const int brc = device_build(c, v.data(), nn.data(), nullptr, me.n_triangles, 0u, B.bvh.nodes8, B.bvh.depth8,
+                                             &c->tri_records[12 * (size_t)B.slot_base], &c->nrm_records[12 * (size_t)B.slot_base], nullptr);
+                if (brc) return brc;
+                continue;
+            }
+            if (!bvh_build(v.data(), me.n_triangles, kMaxLeaf, 0, kMaxStack, &B.bvh) || B.bvh.nodes8.empty())
+                return fail(c, PRT_ERR_INVALID, "instanced mesh %u: BVH construction failed", m);
             for (uint32_t sl = 0; sl < me.n_triangles; ++sl) {
                 const uint32_t t = B.bvh.order[sl];
                 float* r = &c->tri_records[12 * ((size_t)B.slot_base + sl)];
@@ -911,8 +945,15 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
             memcpy(&pv[9 * (size_t)i], tri, sizeof(tri));
         }
         BvhBuild top;
-        if (!bvh_build(pv.data(), n_inst_total, kMaxLeaf, 1, kMaxStack, &top) || top.nodes8.empty())
+        if (gpu_any) {  // the same device builder over the copies' boxes; a record's primitive index is the instance it stands for
+            std::vector<float> rec(12 * (size_t)n_inst_total);
+            const int brc = device_build(c, pv.data(), nullptr, nullptr, n_inst_total, 0u, top.nodes8, top.depth8, rec.data(), nullptr, nullptr);
+            if (brc) return brc;
+            top.order.resize(n_inst_total);
+            for (uint32_t sl = 0; sl < n_inst_total; ++sl) memcpy(&top.order[sl], &rec[12 * (size_t)sl + 3], 4);
+        } else if (!bvh_build(pv.data(), n_inst_total, kMaxLeaf, 1, kMaxStack, &top) || top.nodes8.empty()) {
             return fail(c, PRT_ERR_INVALID, "top-level BVH construction failed");
+        }
         c->tlas_inst = top.order;
         // one node array: [top level][world meshes' tree][instanced meshes' trees]; child_base / tri_base made absolute
         c->nodes8_all = top.nodes8;
@@ -961,13 +1002,14 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         bi.depth8 = top.depth8 + max_blas_depth;
         bi.n_triangles = (uint32_t)slots;
         bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
+        if (gpu_any) bi.build_ms = (float)c->gpu_build_ms;  // world meshes + every placed mesh + the top level, device time
     }
-    c->scene_device_built = gpu_build;
+    c->scene_device_built = gpu_build || (gpu_any && s->n_instances != 0u);
     if (!c->has_device) {  // host-only context: BVH built, nothing to upload
         c->has_scene = true;
         return PRT_OK;
     }
-    return upload_scene(c, gpu_build ? &gb : nullptr);
+    return upload_scene(c, (gpu_build && s->n_instances == 0) ? &gb : nullptr);
 }
 
 // Replicates the scene of `src` (host copies of the flattened primitives, trees and triangle records) onto the device

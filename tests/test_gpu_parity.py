@@ -606,6 +606,40 @@ def test_device_built_tree_renders_the_same_image():
     assert np.array_equal(imgs[0][0], imgs[1][0]) and imgs[0][1] == imgs[1][1]
 
 
+@pytest.mark.parametrize("with_world_mesh", [False, True])
+def test_device_built_two_level_tree_gives_the_same_hits_and_image(with_world_mesh):
+    """gpu_build = 1 on a scene with placed copies: every instanced mesh's tree (in its own space), the world-space meshes'
+    tree and the top-level tree over the copies' boxes come from the device builder; hits bit-exact against the oracle's
+    brute-force scan over all placed triangles, image bit-exact against the oracle and against the host-built scene."""
+    mesh = prt.scenes.refined("bunny.ply", 12_000)
+    scene = _instanced_scene(mesh, with_world_mesh)
+    W, H, spp, depth = 128, 72, 2, 5
+    cam = prt.Camera(position=(6.0, 4.0, 9.0), width=W, height=H)
+    films = []
+    for gpu_build in (1, 0):
+        r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=11)
+        r.set_param("gpu_build", gpu_build)
+        film = prt.Film(W, H)
+        r.Init(film, scene, cam)
+        info = r.bvh_info()
+        assert info.built_on_device == gpu_build and info.n_nodes8 > 0 and info.depth8 <= 12
+        if gpu_build:
+            assert info.build_ms > 0
+            rng = np.random.default_rng(23)
+            o, d = util.random_rays(rng, 4000, center=(0, 0.5, 0), radius=11.0, spread=4.5)
+            got = r.closest_hit(o, d)
+            want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
+            assert util.hits_equal(got, want) == []
+            assert (got["prim"] >= 2).sum() > 500
+        r.ProgressiveRender(spp)
+        r.download()
+        films.append((film.accum.copy(), r.stats().rays_total))
+    assert np.array_equal(films[0][0], films[1][0]) and films[0][1] == films[1][1]
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=11, iterative=True,
+                                                     use_bvh=True, n_threads=8)
+    assert np.array_equal(films[0][0], acc) and films[0][1] == rays
+
+
 def test_kernel_occupancy_report():
     """prt_kernel_occupancy: the static wavefront occupancy bench.py reports next to the roofline."""
     scene = prt.scenes.mesh_scene(prt.Mesh(prt.scenes.asset("bunny.ply")))
