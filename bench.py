@@ -326,13 +326,23 @@ def main():
         sq_p, sq_src = newest_profile("*_sq.json", match)
         traffic = traffic_p.get("hbm_bytes_per_launch") if traffic_p else None
         occ = r.kernel_occupancy()
+        # the roof the kernel is closest to: vector-instruction issue on the cache-resident configs (C2-C4), the fabric /
+        # HBM side once the tree outgrows the 256 MB Infinity Cache (C5); both fractions are always in the line
+        hbm_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
+        valu_frac = achieved / VALU_PEAK_GINST
+        if hbm_frac is not None and hbm_frac > valu_frac:
+            head = {"bound": "hbm", "achieved": round(traffic / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_frac, 4)}
+        else:
+            head = {"bound": "valu", "achieved": round(achieved, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                    "frac": round(valu_frac, 4)}
         roofline = {
-            "bound": "valu", "achieved": round(achieved, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-            "frac": round(achieved / VALU_PEAK_GINST, 4),
+            **head,
             "traffic": traffic, "traffic_note": (traffic_src + ": " + traffic_p.get("note", "")) if traffic_p else traffic_src,
             "kernel": kernel_name, "kernel_instance": inst,
             "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),
-            "valu": {"alg_insts_per_launch": int(valu_alg),
+            "valu": {"achieved_Ginst_s": round(achieved, 2), "peak_Ginst_s": VALU_PEAK_GINST, "frac": round(valu_frac, 4),
+                     "alg_insts_per_launch": int(valu_alg),
                      "node_wave_steps_per_launch": int(node_wave_steps_sample * per_launch),
                      "triangle_rounds_per_launch": int(tri_rounds_sample * per_launch),
                      "valu_per_node_step": isa["node_step"], "valu_per_triangle_round": isa["triangle_round"],
@@ -345,7 +355,7 @@ def main():
                      "sq_source": sq_src},
             "hbm": {"alg_bytes_per_launch": int(bytes_per_launch), "alg_GBs": round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1),
                     "traffic_bytes_per_launch": traffic,
-                    "hbm_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "hbm_frac": round(hbm_frac, 4) if hbm_frac is not None else None,
                     "peak_GBs": HBM_PEAK_GBS, "node_bytes": node_bytes,
                     "note": "alg = 80 B x node visits + 48 B x triangle tests + 44 B x walked rays; served mostly by L2 / Infinity "
                             "Cache on C2-C4 (so alg_GBs may exceed the HBM peak); hbm_frac = fabric-side counter bytes / time / peak"},
