@@ -16,3 +16,7 @@ struct PrtGpuBvh {
 // cmin / cmax: bounds of the triangle centroids.  Returns 0 on success (synchronous: the stream is drained).
 int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
                        uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out);
+// The quality builder (round 2): the same Morton sort, then PLOC (locally-ordered agglomerative clustering) for the binary
+// topology and the SAH-optimal collapse to 8-wide nodes by dynamic programming, all on the device.  Same contract.
+int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
+                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out);

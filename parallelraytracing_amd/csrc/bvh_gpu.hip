@@ -19,9 +19,14 @@
 // Results are tree-independent by construction (closest hit = min world d^2, ties to the lowest primitive index), so
 // the parity tests run unchanged against trees from this builder.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 
 #include "bvh_gpu.h"
@@ -277,6 +282,368 @@ __global__ void k_records(const float* __restrict__ verts, const float* __restri
     nrms[3 * (size_t)slot + 2] = make_float4(q[6], q[7], q[8], 0.0f);
 }
 
+
+// =========================================================================================================
+// Quality builder (round 2): PLOC binary tree + SAH-optimal collapse to the 8-wide layout, all on the device.
+//
+// The Morton octree above builds in ~7 ms but its trees traverse ~20 % slower than the host's binned-SAH tree (median
+// splits, 4.5 of 8 slots filled).  This builder keeps the Morton sort and replaces the topology:
+//   1. PLOC (parallel locally-ordered clustering, Meister & Bittner 2018; re-derived here): the clusters, in Morton order,
+//      each look RADIUS positions to both sides for the partner that minimises the surface area of the merged box;
+//      mutual nearest neighbours merge into a new binary node; the cluster array is compacted (one 64-bit scan gives the
+//      new node ids and the compacted positions) and the pass repeats until one cluster is left (~45 passes for 870 k).
+//      A node's children always have smaller ids than the node, and every pass's nodes form one contiguous id range.
+//   2. The same dynamic programme as the host's collapse (bvh.cpp; after Ylitie et al. 2017, section 3), pass range by
+//      pass range bottom-up: cost[n][i] = least cost of representing the subtree of n in at most i + 1 slots of its wide
+//      parent, cost = area of the wide nodes created + CI x triangles x area of the leaves; subtrees of <= 3 triangles may
+//      become leaves (PLOC's tree goes down to single triangles, the leaves are part of the optimisation here).
+//   3. Emission level by level, breadth first (one launch per level, as above): a wide node's children follow from the
+//      DP's picks, go to octant-ordered slots by the host's greedy rule, internal children get consecutive indices from one
+//      atomic, leaf triangles consecutive slots from another; quantization as in k_quantize (double precision, contained).
+// =========================================================================================================
+#define PLOC_RADIUS_MAX 64
+static int g_ploc_radius = 24;   // search radius in Morton order (PRT_PLOC_RADIUS; tuned on C3, tools/build_compare.py)
+static float g_ploc_ci = 0.6f;   // cost of one triangle test relative to one 8-wide node visit (PRT_PLOC_CI)
+
+__device__ __forceinline__ float half_area6(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// leaves of the binary tree = the triangles in Morton order: node i (< n) is sorted triangle i
+__global__ void k_ploc_leaves(const float* __restrict__ verts, const uint32_t* __restrict__ sorted_idx, uint32_t n,
+                              float* __restrict__ box, int* __restrict__ left, int* __restrict__ right, uint32_t* __restrict__ cnt,
+                              uint32_t* __restrict__ cl) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* v = verts + 9 * (size_t)sorted_idx[i];
+    for (int a = 0; a < 3; ++a) {
+        box[6 * (size_t)i + a] = fminf(v[a], fminf(v[3 + a], v[6 + a]));
+        box[6 * (size_t)i + 3 + a] = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    }
+    left[i] = right[i] = -1;
+    cnt[i] = 1u;
+    cl[i] = i;
+}
+
+// nearest neighbour of every cluster within PLOC_RADIUS positions (merged-box area; ties to the lower position, which
+// makes "mutual" well defined: the globally best pair is always mutual, so every pass merges at least one pair)
+__global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ box,
+                                                 uint32_t* __restrict__ nn, int PLOC_RADIUS) {
+    __shared__ float s_box[(256 + 2 * PLOC_RADIUS_MAX) * 6];
+    const int base = (int)(blockIdx.x * 256u) - PLOC_RADIUS;
+    for (int t = (int)threadIdx.x; t < 256 + 2 * PLOC_RADIUS; t += 256) {
+        const int j = base + t;
+        if (j >= 0 && j < (int)m) {
+            const float* b = box + 6 * (size_t)cl[j];
+            for (int a = 0; a < 6; ++a) s_box[6 * t + a] = b[a];
+        }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const float* bi = &s_box[6 * ((int)threadIdx.x + PLOC_RADIUS)];
+    float best = 3.402823466e+38f;
+    uint32_t bj = i;
+    const int j0 = (int)i - PLOC_RADIUS < 0 ? 0 : (int)i - PLOC_RADIUS;
+    const int j1 = (int)i + PLOC_RADIUS >= (int)m ? (int)m - 1 : (int)i + PLOC_RADIUS;
+    for (int j = j0; j <= j1; ++j) {
+        if (j == (int)i) continue;
+        const float* bq = &s_box[6 * (j - base)];
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(bi[a], bq[a]);
+            hi[a] = fmaxf(bi[3 + a], bq[3 + a]);
+        }
+        const float ar = half_area6(lo, hi);
+        if (ar < best) {  // strict: ties keep the lower position
+            best = ar;
+            bj = (uint32_t)j;
+        }
+    }
+    nn[i] = bj;
+}
+
+// flags for the scan: low word = 1 for the leader of a mutual pair (the lower position), high word = 1 for every
+// cluster that stays in the array (everything except the higher position of a mutual pair)
+__global__ void k_ploc_flags(const uint32_t* __restrict__ nn, uint32_t m, unsigned long long* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    const unsigned long long leader = (mutual && i < j) ? 1ull : 0ull, keep = (mutual && i > j) ? 0ull : 1ull;
+    flags[i] = leader | (keep << 32);
+}
+
+__global__ void k_ploc_merge(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ nn, const unsigned long long* __restrict__ scan,
+                             uint32_t m, uint32_t node_base, uint32_t* __restrict__ cl_out, float* __restrict__ box,
+                             int* __restrict__ left, int* __restrict__ right, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    if (mutual && i > j) return;  // absorbed by its partner
+    const unsigned long long sc = scan[i];
+    uint32_t id = cl[i];
+    if (mutual) {
+        const uint32_t a = cl[i], b = cl[j];
+        id = node_base + (uint32_t)(sc & 0xFFFFFFFFull);
+        for (int k = 0; k < 3; ++k) {
+            box[6 * (size_t)id + k] = fminf(box[6 * (size_t)a + k], box[6 * (size_t)b + k]);
+            box[6 * (size_t)id + 3 + k] = fmaxf(box[6 * (size_t)a + 3 + k], box[6 * (size_t)b + 3 + k]);
+        }
+        left[id] = (int)a;
+        right[id] = (int)b;
+        cnt[id] = cnt[a] + cnt[b];
+    }
+    cl_out[(uint32_t)(sc >> 32)] = id;
+}
+
+// rows of the remaining clusters, contiguous, for the host's top builder
+__global__ void k_ploc_gather(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ box, const uint32_t* __restrict__ cnt,
+                              const float* __restrict__ cost, float* __restrict__ o_box, uint32_t* __restrict__ o_cnt, float* __restrict__ o_cost) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t id = cl[i];
+    for (int a = 0; a < 6; ++a) o_box[6 * (size_t)i + a] = box[6 * (size_t)id + a];
+    for (int a = 0; a < 8; ++a) o_cost[8 * (size_t)i + a] = cost[8 * (size_t)id + a];
+    o_cnt[i] = cnt[id];
+}
+
+#define PLOC_LEAF 0xFFu  // pick value: "this subtree is one leaf"
+// The collapse DP for the binary nodes [nb, ne) of one PLOC pass (their children belong to earlier passes).
+// cost[n][i], i = 0..6 <-> 1..7 slots of the wide parent; [n][7] is unused (pick[n][7] = split of n's own 8 slots).
+__host__ __device__ inline float ploc_half_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// One node of the DP.  cl / cr: the children's cost rows (null for a single triangle), c: triangles below the node.
+__host__ __device__ inline void ploc_dp_node(const float* bx, uint32_t c, const float* cl, const float* cr, float ci, float* cn, uint8_t* pn) {
+    const float area = ploc_half_area(bx);
+    if (!cl) {  // a single triangle: one slot, one test
+        for (int i = 0; i < 8; ++i) {
+            cn[i] = ci * area;
+            pn[i] = PLOC_LEAF;
+        }
+        return;
+    }
+    float dist[9];
+    uint8_t dk[9];
+    for (int j = 2; j <= 8; ++j) {  // distribute j slots over the two children
+        float bestc = 3.402823466e+38f;
+        int bk = 1;
+        for (int k = 1; k < j; ++k) {
+            const int a = (k < 7 ? k : 7) - 1, b = (j - k < 7 ? j - k : 7) - 1;
+            const float v = cl[a] + cr[b];
+            if (v < bestc) {
+                bestc = v;
+                bk = k;
+            }
+        }
+        dist[j] = bestc;
+        dk[j] = (uint8_t)bk;
+    }
+    const float leaf_cost = c <= 3u ? ci * (float)c * area : 3.402823466e+38f;
+    // one slot: a leaf, or a wide node of its own (its children take its 8 slots)
+    const float own = dist[8] + area;
+    cn[0] = leaf_cost <= own ? leaf_cost : own;
+    pn[0] = leaf_cost <= own ? PLOC_LEAF : 0u;
+    pn[7] = dk[8];
+    cn[7] = dist[8];
+    for (int i = 2; i <= 7; ++i) {  // i slots: split over the children, or do with i - 1 slots
+        if (dist[i] < cn[i - 2]) {
+            cn[i - 1] = dist[i];
+            pn[i - 1] = dk[i];
+        } else {
+            cn[i - 1] = cn[i - 2];
+            pn[i - 1] = pn[i - 2] == PLOC_LEAF ? PLOC_LEAF : 0u;
+        }
+    }
+}
+__global__ void k_ploc_dp(uint32_t nb, uint32_t ne, uint32_t n_leaves, const int* __restrict__ left, const int* __restrict__ right,
+                          const float* __restrict__ box, const uint32_t* __restrict__ cnt, float* __restrict__ cost,
+                          uint8_t* __restrict__ pick, float PLOC_CI) {
+    const uint32_t nd = nb + blockIdx.x * 128u + threadIdx.x;
+    if (nd >= ne) return;
+    const bool tri = nd < n_leaves;
+    ploc_dp_node(box + 6 * (size_t)nd, cnt[nd], tri ? nullptr : cost + 8 * (size_t)left[nd], tri ? nullptr : cost + 8 * (size_t)right[nd],
+                 PLOC_CI, cost + 8 * (size_t)nd, pick + 8 * (size_t)nd);
+}
+
+// Emission of the wide nodes [wb, we) of one level.  wroot[w] = binary node whose subtree wide node w represents.
+__global__ void k_ploc_emit(uint32_t wb, uint32_t we, uint32_t n_leaves, uint32_t max_nodes, uint32_t* __restrict__ wroot,
+                            const int* __restrict__ left, const int* __restrict__ right, const float* __restrict__ box,
+                            const uint32_t* __restrict__ cnt, const uint8_t* __restrict__ pick, const uint32_t* __restrict__ sorted_idx,
+                            uint32_t* __restrict__ nodes8, uint32_t* __restrict__ order, uint32_t* __restrict__ counters) {
+    const uint32_t w = wb + blockIdx.x * 64u + threadIdx.x;
+    if (w >= we) return;
+    const uint32_t R = wroot[w];
+    // ---- children of the wide node: walk the binary tree below R handing out R's 8 slots by the DP's picks ----
+    uint32_t kids[8];
+    bool kid_leaf[8];
+    int n = 0;
+    if (R < n_leaves || (w == 0u && pick[8 * (size_t)R] == PLOC_LEAF)) {
+        kids[n] = R;  // a mesh of <= 3 triangles: the root holds one leaf child
+        kid_leaf[n++] = true;
+    } else {
+        uint32_t st_node[8];
+        int st_slots[8], top = 0;
+        const int k8 = pick[8 * (size_t)R + 7];
+        st_node[top] = (uint32_t)right[R];
+        st_slots[top++] = 8 - k8;
+        st_node[top] = (uint32_t)left[R];
+        st_slots[top++] = k8;
+        while (top > 0) {
+            --top;
+            const uint32_t nd = st_node[top];
+            const int slots = st_slots[top];
+            if (nd < n_leaves) {
+                kids[n] = nd;
+                kid_leaf[n++] = true;
+                continue;
+            }
+            int i = slots < 7 ? slots : 7;
+            const uint8_t* pn = pick + 8 * (size_t)nd;
+            while (i > 1 && pn[i - 1] == 0u) --i;  // "use fewer slots"
+            if (pn[i - 1] == PLOC_LEAF) {  // the whole subtree (<= 3 triangles) is one leaf child
+                kids[n] = nd;
+                kid_leaf[n++] = true;
+                continue;
+            }
+            if (i == 1) {  // stays an internal child: a wide node of its own
+                kids[n] = nd;
+                kid_leaf[n++] = false;
+                continue;
+            }
+            const int k = pn[i - 1];
+            st_node[top] = (uint32_t)right[nd];
+            st_slots[top++] = i - k;
+            st_node[top] = (uint32_t)left[nd];
+            st_slots[top++] = k;
+        }
+    }
+    const float* nbx = box + 6 * (size_t)R;
+    // ---- slots (bvh.cpp): slot s is visited first by rays whose direction is negative exactly on the axes whose bit is
+    // set in s: greedy on dot(child centre - node centre, that diagonal) ----
+    int slot_of[8], child_in[8];
+    float score[8][8];
+    for (int k = 0; k < 8; ++k) slot_of[k] = child_in[k] = -1;
+    for (int c = 0; c < n; ++c) {
+        const float* cb = box + 6 * (size_t)kids[c];
+        float d[3];
+        for (int a = 0; a < 3; ++a) d[a] = (0.5f * cb[a] + 0.5f * cb[3 + a]) - (0.5f * nbx[a] + 0.5f * nbx[3 + a]);
+        for (int sl = 0; sl < 8; ++sl)
+            score[c][sl] = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+    }
+    for (int round = 0; round < n; ++round) {
+        int bc = -1, bs = -1;
+        float best = -3.402823466e+38f;
+        for (int c = 0; c < n; ++c) {
+            if (slot_of[c] >= 0) continue;
+            for (int sl = 0; sl < 8; ++sl)
+                if (child_in[sl] < 0 && (bc < 0 || score[c][sl] > best)) {
+                    best = score[c][sl];
+                    bc = c;
+                    bs = sl;
+                }
+        }
+        slot_of[bc] = bs;
+        child_in[bs] = bc;
+    }
+    // ---- indices: internal children consecutive from one atomic, leaf triangles consecutive from another ----
+    uint32_t n_int = 0, n_leaf_tris = 0;
+    for (int c = 0; c < n; ++c) {
+        if (kid_leaf[c]) n_leaf_tris += cnt[kids[c]];
+        else ++n_int;
+    }
+    uint32_t child_base = n_int ? atomicAdd(&counters[0], n_int) : 0u;
+    const uint32_t tri_base = n_leaf_tris ? atomicAdd(&counters[1], n_leaf_tris) : 0u;
+    if (n_int && child_base + n_int > max_nodes) {  // cannot happen (every wide node has >= 2 children); flagged
+        atomicOr(&counters[2], 1u);
+        return;
+    }
+    // ---- quantization grid (k_quantize) ----
+    uint32_t eb[3];
+    double cell[3];
+    for (int a = 0; a < 3; ++a) {
+        const double p = nbx[a], ext = (double)nbx[3 + a] - p;
+        const double big = fmax(fabs((double)nbx[a]), fabs((double)nbx[3 + a]));
+        int e = ext > 0.0 ? (int)ceil(log2(ext / 255.0)) : -126;
+        if (big > 0.0) e = max(e, (int)floor(log2(big)) - 30);
+        e = max(e, -126);
+        while (ceil(ext / ldexp(1.0, e)) > 255.0) ++e;
+        if (e > 126) {
+            atomicOr(&counters[2], 2u);
+            e = 126;
+        }
+        eb[a] = (uint32_t)(e + 127);
+        cell[a] = ldexp(1.0, e);
+    }
+    uint32_t imask = 0, meta[8], q[6][8], rank = 0, off = 0;
+    for (int sl = 0; sl < 8; ++sl) {
+        meta[sl] = 0;
+        for (int a = 0; a < 3; ++a) {
+            q[a][sl] = 255u;  // empty slot: inverted box
+            q[3 + a][sl] = 0u;
+        }
+        const int c = child_in[sl];
+        if (c < 0) continue;
+        const uint32_t kid = kids[c];
+        const float* cb = box + 6 * (size_t)kid;
+        for (int a = 0; a < 3; ++a) {
+            const double p = nbx[a];
+            double l = floor(((double)cb[a] - p) / cell[a]);
+            while (l > 0.0 && p + l * cell[a] > (double)cb[a]) l -= 1.0;
+            if (l < 0.0) l = 0.0;
+            double h = ceil(((double)cb[3 + a] - p) / cell[a]);
+            while (p + h * cell[a] < (double)cb[3 + a]) h += 1.0;
+            if (h > 255.0 || l > h) {
+                atomicOr(&counters[2], 4u);
+                h = 255.0;
+            }
+            q[a][sl] = (uint32_t)l;
+            q[3 + a][sl] = (uint32_t)h;
+        }
+        if (kid_leaf[c]) {
+            const uint32_t kc = cnt[kid];
+            meta[sl] = (((1u << kc) - 1u) << 5) | off;
+            // the <= 3 triangles below kid, in Morton order
+            uint32_t tl[3], nt = 0, stk[4];
+            int tp = 0;
+            stk[tp++] = kid;
+            while (tp > 0) {
+                const uint32_t x = stk[--tp];
+                if (x < n_leaves) {
+                    tl[nt++] = x;
+                } else {
+                    stk[tp++] = (uint32_t)right[x];
+                    stk[tp++] = (uint32_t)left[x];
+                }
+            }
+            for (uint32_t k = 0; k < nt; ++k) order[tri_base + off + k] = sorted_idx[tl[k]];
+            off += kc;
+        } else {
+            imask |= 1u << sl;
+            meta[sl] = (1u << 5) | (24u + (uint32_t)sl);
+        }
+    }
+    for (int sl = 0; sl < 8; ++sl)  // the internal children get consecutive node indices in slot order
+        if ((imask >> sl) & 1u) wroot[child_base + rank++] = kids[child_in[sl]];
+    uint32_t* wd = nodes8 + 20 * (size_t)w;
+    wd[0] = __float_as_uint(nbx[0]);
+    wd[1] = __float_as_uint(nbx[1]);
+    wd[2] = __float_as_uint(nbx[2]);
+    wd[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
+    wd[4] = child_base;
+    wd[5] = tri_base;
+    wd[6] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24);
+    wd[7] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24);
+    for (int pl = 0; pl < 6; ++pl) {
+        wd[8 + 2 * pl] = q[pl][0] | (q[pl][1] << 8) | (q[pl][2] << 16) | (q[pl][3] << 24);
+        wd[9 + 2 * pl] = q[pl][4] | (q[pl][5] << 8) | (q[pl][6] << 16) | (q[pl][7] << 24);
+    }
+}
+
 }  // namespace
 
 int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
@@ -378,4 +745,292 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
     out->n_nodes = n_nodes;
     out->depth = n_levels;
     return 0;
+#undef GB_TRY
+}
+
+
+// PLOC's weak spot is the TOP of the tree: big clusters that are far apart in Morton order never see each other, and the
+// top levels are what every ray visits.  The passes therefore stop when at most PLOC_TOP clusters are left, and the tree
+// above them is built on the host by a full-sweep SAH over those few thousand boxes (weights = their triangle counts):
+// microseconds of work, and the upper levels get the splits a top-down builder would choose.
+#define PLOC_TOP 4096u
+namespace {
+struct TopBuilder {
+    const float* cbox;       // [m][6] boxes of the remaining clusters
+    const uint32_t* ccnt;    // [m] triangles per cluster
+    const uint32_t* cid;     // [m] their binary node ids
+    std::vector<int> left, right;  // new nodes, in creation (post) order
+    std::vector<float> box;
+    std::vector<uint32_t> cnt;
+    uint32_t next_id;
+    // builds the subtree over items[lo, hi) (indices into the cluster arrays); returns the binary node id of its root
+    uint32_t build(std::vector<uint32_t>& items, size_t lo, size_t hi) {
+        if (hi - lo == 1) return cid[items[lo]];
+        float bb[6] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                bb[a] = std::min(bb[a], cbox[6 * (size_t)items[i] + a]);
+                bb[3 + a] = std::max(bb[3 + a], cbox[6 * (size_t)items[i] + 3 + a]);
+            }
+        const size_t n = hi - lo;
+        double best = 1e300;
+        int best_axis = 0;
+        size_t best_split = n / 2;
+        std::vector<uint32_t> sorted(items.begin() + (long)lo, items.begin() + (long)hi);
+        std::vector<double> right_cost(n);
+        auto by_axis = [&](int axis) {
+            std::sort(sorted.begin(), sorted.end(), [&](uint32_t x, uint32_t y) {
+                const float cx = cbox[6 * (size_t)x + axis] + cbox[6 * (size_t)x + 3 + axis], cy = cbox[6 * (size_t)y + axis] + cbox[6 * (size_t)y + 3 + axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+        };
+        for (int axis = 0; axis < 3; ++axis) {
+            by_axis(axis);
+            float rb[6] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            double rc = 0.0;
+            for (size_t i = n; i-- > 1;) {  // right part = sorted[i .. n)
+                for (int a = 0; a < 3; ++a) {
+                    rb[a] = std::min(rb[a], cbox[6 * (size_t)sorted[i] + a]);
+                    rb[3 + a] = std::max(rb[3 + a], cbox[6 * (size_t)sorted[i] + 3 + a]);
+                }
+                rc += ccnt[sorted[i]];
+                right_cost[i] = (double)ploc_half_area(rb) * rc;
+            }
+            float lb[6] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            double lc = 0.0;
+            for (size_t i = 0; i + 1 < n; ++i) {  // left part = sorted[0 .. i]
+                for (int a = 0; a < 3; ++a) {
+                    lb[a] = std::min(lb[a], cbox[6 * (size_t)sorted[i] + a]);
+                    lb[3 + a] = std::max(lb[3 + a], cbox[6 * (size_t)sorted[i] + 3 + a]);
+                }
+                lc += ccnt[sorted[i]];
+                const double c = (double)ploc_half_area(lb) * lc + right_cost[i + 1];
+                if (c < best) {
+                    best = c;
+                    best_axis = axis;
+                    best_split = i + 1;
+                }
+            }
+        }
+        by_axis(best_axis);  // (the comparator is a strict total order: the same permutation as when the split was found)
+        std::copy(sorted.begin(), sorted.end(), items.begin() + (long)lo);
+        const uint32_t l = build(items, lo, lo + best_split);
+        const uint32_t r = build(items, lo + best_split, hi);
+        uint32_t c = 0;
+        for (size_t i = lo; i < hi; ++i) c += ccnt[items[i]];
+        left.push_back((int)l);
+        right.push_back((int)r);
+        box.insert(box.end(), bb, bb + 6);
+        cnt.push_back(c);
+        return next_id++;  // children were created first: their ids are smaller
+    }
+};
+}  // namespace
+
+// The quality builder: Morton sort + PLOC + optimal collapse (see the block comment above k_ploc_leaves).  Same contract
+// as prt_gpu_bvh8_build.
+int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
+                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out) {
+    out->n_nodes = 0;
+    out->depth = 0;
+    out->d_nodes8 = nullptr;
+    out->d_tris = out->d_nrms = nullptr;
+    if (n_tris == 0) return 0;
+    if (const char* e = getenv("PRT_PLOC_RADIUS")) g_ploc_radius = std::min(PLOC_RADIUS_MAX, std::max(1, atoi(e)));
+    if (const char* e = getenv("PRT_PLOC_CI")) g_ploc_ci = (float)atof(e);
+    const uint32_t n = n_tris;
+    const uint32_t n_bin = 2u * n;  // binary nodes: n leaves + n - 1 internal
+    const uint32_t max_nodes = n + 16u;
+    uint32_t *codes = nullptr, *codes2 = nullptr, *idx = nullptr, *idx2 = nullptr, *order = nullptr, *counters = nullptr;
+    uint32_t *cl_a = nullptr, *cl_b = nullptr, *nn = nullptr, *cnt = nullptr, *wroot = nullptr, *nodes8 = nullptr;
+    unsigned long long *flags = nullptr, *scan = nullptr;
+    int *left = nullptr, *right = nullptr;
+    float *box = nullptr, *cost = nullptr;
+    uint8_t* pick = nullptr;
+    void *temp = nullptr, *temp2 = nullptr;
+    float4 *tris = nullptr, *nrms = nullptr;
+    auto cleanup = [&](bool keep) {
+        for (void* p : {(void*)codes, (void*)codes2, (void*)idx, (void*)idx2, (void*)order, (void*)counters, (void*)cl_a, (void*)cl_b,
+                        (void*)nn, (void*)cnt, (void*)wroot, (void*)flags, (void*)scan, (void*)left, (void*)right, (void*)box,
+                        (void*)cost, (void*)pick, temp, temp2})
+            (void)hipFree(p);
+        if (!keep) {
+            (void)hipFree(nodes8);
+            (void)hipFree(tris);
+            (void)hipFree(nrms);
+        }
+    };
+#define GB_TRY(x)                   \
+    do {                            \
+        hipError_t e_ = (x);        \
+        if (e_ != hipSuccess) {     \
+            cleanup(false);         \
+            return (int)e_;         \
+        }                           \
+    } while (0)
+    GB_TRY(hipMalloc((void**)&codes, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&codes2, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&idx, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&idx2, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&order, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&counters, 16));
+    GB_TRY(hipMalloc((void**)&cl_a, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&cl_b, 4 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&nn, std::max<size_t>(4 * (size_t)n, 4 * (size_t)PLOC_TOP)));
+    GB_TRY(hipMalloc((void**)&flags, std::max<size_t>(8 * (size_t)n, 32 * (size_t)PLOC_TOP)));  // (also the top builder's gather buffers)
+    GB_TRY(hipMalloc((void**)&scan, std::max<size_t>(8 * (size_t)n, 32 * (size_t)PLOC_TOP)));
+    GB_TRY(hipMalloc((void**)&cnt, 4 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&left, 4 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&right, 4 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&box, 24 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&cost, 32 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&pick, 8 * (size_t)n_bin));
+    GB_TRY(hipMalloc((void**)&wroot, 4 * (size_t)max_nodes));
+    GB_TRY(hipMalloc((void**)&nodes8, 80 * (size_t)max_nodes));
+    GB_TRY(hipMalloc((void**)&tris, 48 * (size_t)n));
+    GB_TRY(hipMalloc((void**)&nrms, 48 * (size_t)n));
+    // 1. Morton codes + sort
+    float3 mn = make_float3(cmin[0], cmin[1], cmin[2]);
+    float3 inv;
+    inv.x = cmax[0] > cmin[0] ? 1024.0f / (cmax[0] - cmin[0]) : 0.0f;
+    inv.y = cmax[1] > cmin[1] ? 1024.0f / (cmax[1] - cmin[1]) : 0.0f;
+    inv.z = cmax[2] > cmin[2] ? 1024.0f / (cmax[2] - cmin[2]) : 0.0f;
+    hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, n, mn, inv, codes, idx);
+    size_t temp_bytes = 0;
+    GB_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes, codes2, idx, idx2, n, 0, 30, st));
+    GB_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+    GB_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, codes, codes2, idx, idx2, n, 0, 30, st));
+    // 2. PLOC
+    hipLaunchKernelGGL(k_ploc_leaves, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, idx2, n, box, left, right, cnt, cl_a);
+    size_t scan_bytes = 0;
+    GB_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
+    GB_TRY(hipMalloc(&temp2, scan_bytes ? scan_bytes : 16));
+    std::vector<uint32_t> pass_begin;  // binary node id ranges created per pass
+    uint32_t m = n, next_node = n;
+    uint32_t* cl_in = cl_a;
+    uint32_t* cl_out = cl_b;
+    pass_begin.push_back(n);
+    for (uint32_t pass = 0; m > PLOC_TOP; ++pass) {
+        if (pass > 4096u) {  // every pass merges at least the globally best pair: cannot happen
+            cleanup(false);
+            return -4;
+        }
+        const dim3 g((m + 255u) / 256u), b(256);
+        hipLaunchKernelGGL(k_ploc_nn, g, b, 0, st, cl_in, m, box, nn, g_ploc_radius);
+        hipLaunchKernelGGL(k_ploc_flags, g, b, 0, st, nn, m, flags);
+        size_t sb = scan_bytes;
+        GB_TRY(rocprim::exclusive_scan(temp2, sb, flags, scan, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), st));
+        hipLaunchKernelGGL(k_ploc_merge, g, b, 0, st, cl_in, nn, scan, m, next_node, cl_out, box, left, right, cnt);
+        unsigned long long last_scan = 0, last_flag = 0;
+        GB_TRY(hipMemcpyAsync(&last_scan, scan + (m - 1u), 8, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(&last_flag, flags + (m - 1u), 8, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+        const unsigned long long tot = last_scan + last_flag;
+        const uint32_t merged = (uint32_t)(tot & 0xFFFFFFFFull), kept = (uint32_t)(tot >> 32);
+        if (merged == 0u || kept + merged != m) {
+            cleanup(false);
+            return -5;
+        }
+        next_node += merged;
+        pass_begin.push_back(next_node);
+        m = kept;
+        std::swap(cl_in, cl_out);
+    }
+    // 3. collapse DP, bottom-up: the leaves, then pass by pass
+    hipLaunchKernelGGL(k_ploc_dp, dim3((n + 127u) / 128u), dim3(128), 0, st, 0u, n, n, left, right, box, cnt, cost, pick, g_ploc_ci);
+    for (size_t p = 0; p + 1 < pass_begin.size(); ++p) {
+        const uint32_t nb = pass_begin[p], ne = pass_begin[p + 1];
+        if (ne > nb) hipLaunchKernelGGL(k_ploc_dp, dim3((ne - nb + 127u) / 128u), dim3(128), 0, st, nb, ne, n, left, right, box, cnt, cost, pick, g_ploc_ci);
+    }
+    // 2b. the top of the tree over the m remaining clusters: full-sweep SAH on the host, its DP rows as well
+    uint32_t root_bin = 0u;
+    {
+        std::vector<uint32_t> h_cl(m), h_cnt(m);
+        std::vector<float> h_box(6 * (size_t)m), h_cost(8 * (size_t)m);
+        // (the clusters' rows are scattered over the node arrays: gathered on the device into the scan / flag buffers, which
+        // are free now: 8 n bytes each, m <= 4096 rows of 56 B)
+        float* g_box = (float*)flags;
+        float* g_cost = (float*)scan;
+        uint32_t* g_cnt = nn;
+        hipLaunchKernelGGL(k_ploc_gather, dim3((m + 255u) / 256u), dim3(256), 0, st, cl_in, m, box, cnt, cost, g_box, g_cnt, g_cost);
+        GB_TRY(hipMemcpyAsync(h_cl.data(), cl_in, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(h_box.data(), g_box, 24 * (size_t)m, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(h_cnt.data(), g_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(h_cost.data(), g_cost, 32 * (size_t)m, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+        TopBuilder tb;
+        tb.cbox = h_box.data();
+        tb.ccnt = h_cnt.data();
+        tb.cid = h_cl.data();
+        tb.next_id = next_node;
+        std::vector<uint32_t> items(m);
+        for (uint32_t i = 0; i < m; ++i) items[i] = i;
+        root_bin = tb.build(items, 0, m);
+        const uint32_t n_top = tb.next_id - next_node;
+        if (n_top != m - 1u || tb.next_id != (n > 1u ? 2u * n - 1u : 1u)) {
+            cleanup(false);
+            return -6;
+        }
+        if (n_top) {
+            // DP rows of the top nodes, in creation order (children first); a child is a cluster (row copied above) or
+            // an earlier top node
+            std::vector<float> t_cost(8 * (size_t)n_top);
+            std::vector<uint8_t> t_pick(8 * (size_t)n_top);
+            std::vector<uint32_t> slot_of_id;  // cluster node id -> index into h_cost: via a sorted lookup
+            std::vector<std::pair<uint32_t, uint32_t>> lut(m);
+            for (uint32_t i = 0; i < m; ++i) lut[i] = {h_cl[i], i};
+            std::sort(lut.begin(), lut.end());
+            auto row = [&](int id) -> const float* {
+                if ((uint32_t)id >= next_node) return &t_cost[8 * (size_t)((uint32_t)id - next_node)];
+                const auto it = std::lower_bound(lut.begin(), lut.end(), std::make_pair((uint32_t)id, 0u));
+                return &h_cost[8 * (size_t)it->second];
+            };
+            for (uint32_t k = 0; k < n_top; ++k)
+                ploc_dp_node(&tb.box[6 * (size_t)k], tb.cnt[k], row(tb.left[k]), row(tb.right[k]), g_ploc_ci, &t_cost[8 * (size_t)k], &t_pick[8 * (size_t)k]);
+            GB_TRY(hipMemcpyAsync(left + next_node, tb.left.data(), 4 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(right + next_node, tb.right.data(), 4 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(box + 6 * (size_t)next_node, tb.box.data(), 24 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(cnt + next_node, tb.cnt.data(), 4 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(cost + 8 * (size_t)next_node, t_cost.data(), 32 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(pick + 8 * (size_t)next_node, t_pick.data(), 8 * (size_t)n_top, hipMemcpyHostToDevice, st));
+            GB_TRY(hipStreamSynchronize(st));  // (the host vectors go out of scope below)
+        }
+    }
+    // 4. emission, breadth first
+    const uint32_t init[4] = {1u, 0u, 0u, 0u};  // wide node count (the root exists), triangle cursor, error flags
+    GB_TRY(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, st));
+    GB_TRY(hipMemcpyAsync(wroot, &root_bin, 4, hipMemcpyHostToDevice, st));
+    uint32_t n_levels = 0, begin = 0, end = 1;
+    while (begin < end && n_levels < 63u) {
+        ++n_levels;
+        hipLaunchKernelGGL(k_ploc_emit, dim3((end - begin + 63u) / 64u), dim3(64), 0, st, begin, end, n, max_nodes, wroot, left, right, box,
+                           cnt, pick, idx2, nodes8, order, counters);
+        uint32_t c4[4];
+        GB_TRY(hipMemcpyAsync(c4, counters, sizeof(c4), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+        if (c4[2]) {
+            cleanup(false);
+            return -2;
+        }
+        begin = end;
+        end = c4[0];
+    }
+    const uint32_t n_nodes = end;
+    hipLaunchKernelGGL(k_records, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, d_norms, d_tri_mat, order, n, n_prims, tris, nrms);
+    uint32_t c4[4];
+    GB_TRY(hipMemcpyAsync(c4, counters, sizeof(c4), hipMemcpyDeviceToHost, st));
+    GB_TRY(hipStreamSynchronize(st));
+    GB_TRY(hipGetLastError());
+    if (c4[2] || c4[1] != n) {
+        cleanup(false);
+        return -3;
+    }
+    cleanup(true);
+    out->d_nodes8 = nodes8;
+    out->d_tris = tris;
+    out->d_nrms = nrms;
+    out->n_nodes = n_nodes;
+    out->depth = n_levels;
+    return 0;
+#undef GB_TRY
 }

@@ -487,7 +487,10 @@ int device_build(PrtContext* c, const float* verts, const float* norms, const ui
     }
     PrtGpuBvh gb{};
     const auto t0 = std::chrono::steady_clock::now();
-    const int brc = prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb);
+    // gpu_build 1: the quality builder (PLOC + optimal collapse); 2: the Morton octree (fastest build, slower to traverse)
+    const int brc = c->gpu_build == 2
+                        ? prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb)
+                        : prt_gpu_bvh8_build_ploc(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb);
     c->gpu_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     drop();
     if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
@@ -1501,7 +1504,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;
     else if (n == "measure_spp" && value >= 1 && value <= 1024) c->measure_spp = value;
-    else if (n == "gpu_build" && (value == 0 || value == 1)) c->gpu_build = value;
+    else if (n == "gpu_build" && (value == 0 || value == 1 || value == 2)) c->gpu_build = value;
     else if (n == "fuse" && (value == 0 || value == 1)) c->tune.fuse = (uint32_t)value;
     else if (n == "tri_min" && value >= 1 && value <= 1024) c->tune.tri_min = (uint32_t)value;
     else if (n == "refill_min" && value >= 1 && value <= 64) c->tune.refill_min = (uint32_t)value;

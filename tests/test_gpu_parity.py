@@ -563,14 +563,16 @@ def test_headline_frame_one_sample_bit_exact():
 
 
 # ---- device-side builder (prt_set_param("gpu_build", 1)) --------------------------------------------------------------
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("bunny.ply", 70_000)])
-def test_device_built_tree_is_valid_and_gives_the_same_hits(ply, target):
-    """The Morton-ordered 8-wide tree built on the GPU: structurally valid (same checker as the host builder's tree),
-    and - because the closest hit does not depend on the tree - bit-exact hits against the oracle."""
+def test_device_built_tree_is_valid_and_gives_the_same_hits(ply, target, mode):
+    """The 8-wide trees built on the GPU (gpu_build 1: PLOC + optimal collapse, 2: Morton octree): structurally valid (same
+    checker as the host builder's tree), and - because the closest hit does not depend on the tree - bit-exact hits
+    against the oracle."""
     mesh = prt.scenes.refined(ply, target) if target else prt.Mesh(prt.scenes.asset(ply))
     scene = prt.scenes.mesh_scene(mesh)
     r = prt.HipWavefrontRenderer(device=0)
-    r.set_param("gpu_build", 1)
+    r.set_param("gpu_build", mode)
     film = prt.Film(16, 16)
     r.Init(film, scene, prt.Camera(width=16, height=16))
     info = r.bvh_info()
@@ -594,7 +596,7 @@ def test_device_built_tree_renders_the_same_image():
     W, H, spp, depth = 128, 72, 2, 5
     cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
     imgs = []
-    for gpu_build in (0, 1):
+    for gpu_build in (0, 1, 2):
         r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=8)
         r.set_param("gpu_build", gpu_build)
         film = prt.Film(W, H)
@@ -602,8 +604,9 @@ def test_device_built_tree_renders_the_same_image():
         r.ProgressiveRender(spp)
         r.download()
         imgs.append((film.accum.copy(), r.stats().rays_total, r.bvh_info().built_on_device))
-    assert imgs[0][2] == 0 and imgs[1][2] == 1
+    assert imgs[0][2] == 0 and imgs[1][2] == 1 and imgs[2][2] == 1
     assert np.array_equal(imgs[0][0], imgs[1][0]) and imgs[0][1] == imgs[1][1]
+    assert np.array_equal(imgs[0][0], imgs[2][0]) and imgs[0][1] == imgs[2][1]
 
 
 @pytest.mark.parametrize("with_world_mesh", [False, True])

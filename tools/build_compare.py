@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host (binned SAH + optimal collapse) vs device (Morton / octree) builder of the compressed 8-wide tree:
+"""Host (binned SAH + optimal collapse) vs the two device builders (gpu_build 1: PLOC + optimal collapse, 2: Morton octree) of the compressed 8-wide tree:
 build time, tree size, and what the tree costs at traversal time.
   python tools/build_compare.py --config C3 --spp 32"""
 import argparse
@@ -19,7 +19,7 @@ def main():
     import parallelraytracing_amd as prt
     torch.cuda.set_device(0)
     scene, cam, W, H, _, depth = prt.scenes.config(args.config)
-    for gpu_build in (0, 1):
+    for gpu_build in (0, 1, 2):
         film = prt.Film(W, H)
         r = prt.HipWavefrontRenderer(device=0, max_depth=depth)
         r.set_param("gpu_build", gpu_build)
