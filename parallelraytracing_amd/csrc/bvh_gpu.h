@@ -18,5 +18,8 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
                        uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out);
 // The quality builder (round 2): the same Morton sort, then PLOC (locally-ordered agglomerative clustering) for the binary
 // topology and the SAH-optimal collapse to 8-wide nodes by dynamic programming, all on the device.  Same contract.
+// leaf_cost: cost of testing one primitive of a leaf relative to one 8-wide node visit (0 = the builder's default for
+// triangles; large for a top-level tree, whose "primitives" are whole instances that are entered without a box test of
+// their own: every instance then gets a leaf to itself).
 int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
-                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out);
+                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out, float leaf_cost = 0.0f);

@@ -830,7 +830,7 @@ struct TopBuilder {
 // The quality builder: Morton sort + PLOC + optimal collapse (see the block comment above k_ploc_leaves).  Same contract
 // as prt_gpu_bvh8_build.
 int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
-                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out) {
+                            uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out, float leaf_cost) {
     out->n_nodes = 0;
     out->depth = 0;
     out->d_nodes8 = nullptr;
@@ -838,6 +838,7 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
     if (n_tris == 0) return 0;
     if (const char* e = getenv("PRT_PLOC_RADIUS")) g_ploc_radius = std::min(PLOC_RADIUS_MAX, std::max(1, atoi(e)));
     if (const char* e = getenv("PRT_PLOC_CI")) g_ploc_ci = (float)atof(e);
+    const float ploc_ci = leaf_cost > 0.0f ? leaf_cost : g_ploc_ci;
     const uint32_t n = n_tris;
     const uint32_t n_bin = 2u * n;  // binary nodes: n leaves + n - 1 internal
     const uint32_t max_nodes = n + 16u;
@@ -937,10 +938,10 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
         std::swap(cl_in, cl_out);
     }
     // 3. collapse DP, bottom-up: the leaves, then pass by pass
-    hipLaunchKernelGGL(k_ploc_dp, dim3((n + 127u) / 128u), dim3(128), 0, st, 0u, n, n, left, right, box, cnt, cost, pick, g_ploc_ci);
+    hipLaunchKernelGGL(k_ploc_dp, dim3((n + 127u) / 128u), dim3(128), 0, st, 0u, n, n, left, right, box, cnt, cost, pick, ploc_ci);
     for (size_t p = 0; p + 1 < pass_begin.size(); ++p) {
         const uint32_t nb = pass_begin[p], ne = pass_begin[p + 1];
-        if (ne > nb) hipLaunchKernelGGL(k_ploc_dp, dim3((ne - nb + 127u) / 128u), dim3(128), 0, st, nb, ne, n, left, right, box, cnt, cost, pick, g_ploc_ci);
+        if (ne > nb) hipLaunchKernelGGL(k_ploc_dp, dim3((ne - nb + 127u) / 128u), dim3(128), 0, st, nb, ne, n, left, right, box, cnt, cost, pick, ploc_ci);
     }
     // 2b. the top of the tree over the m remaining clusters: full-sweep SAH on the host, its DP rows as well
     uint32_t root_bin = 0u;
@@ -986,7 +987,7 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
                 return &h_cost[8 * (size_t)it->second];
             };
             for (uint32_t k = 0; k < n_top; ++k)
-                ploc_dp_node(&tb.box[6 * (size_t)k], tb.cnt[k], row(tb.left[k]), row(tb.right[k]), g_ploc_ci, &t_cost[8 * (size_t)k], &t_pick[8 * (size_t)k]);
+                ploc_dp_node(&tb.box[6 * (size_t)k], tb.cnt[k], row(tb.left[k]), row(tb.right[k]), ploc_ci, &t_cost[8 * (size_t)k], &t_pick[8 * (size_t)k]);
             GB_TRY(hipMemcpyAsync(left + next_node, tb.left.data(), 4 * (size_t)n_top, hipMemcpyHostToDevice, st));
             GB_TRY(hipMemcpyAsync(right + next_node, tb.right.data(), 4 * (size_t)n_top, hipMemcpyHostToDevice, st));
             GB_TRY(hipMemcpyAsync(box + 6 * (size_t)next_node, tb.box.data(), 24 * (size_t)n_top, hipMemcpyHostToDevice, st));

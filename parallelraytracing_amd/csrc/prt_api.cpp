@@ -457,7 +457,7 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
 // per triangle): nodes and the triangle / normal records in the tree's slot order come back to the host copies the
 // rest of prt_set_scene works with; with `keep` the device arrays stay allocated and are handed to the caller.
 int device_build(PrtContext* c, const float* verts, const float* norms, const uint32_t* tri_mat, uint32_t n, uint32_t n_prims,
-                 std::vector<uint32_t>& nodes8, uint32_t& depth, float* tri_rec, float* nrm_rec, PrtGpuBvh* keep) {
+                 std::vector<uint32_t>& nodes8, uint32_t& depth, float* tri_rec, float* nrm_rec, PrtGpuBvh* keep, float leaf_cost = 0.0f) {
     float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (size_t t = 0; t < (size_t)n; ++t)
         for (int a = 0; a < 3; ++a) {
@@ -490,7 +490,7 @@ int device_build(PrtContext* c, const float* verts, const float* norms, const ui
     // gpu_build 1: the quality builder (PLOC + optimal collapse); 2: the Morton octree (fastest build, slower to traverse)
     const int brc = c->gpu_build == 2
                         ? prt_gpu_bvh8_build(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb)
-                        : prt_gpu_bvh8_build_ploc(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb);
+                        : prt_gpu_bvh8_build_ploc(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb, leaf_cost);
     c->gpu_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     drop();
     if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
@@ -950,7 +950,9 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         BvhBuild top;
         if (gpu_any) {  // the same device builder over the copies' boxes; a record's primitive index is the instance it stands for
             std::vector<float> rec(12 * (size_t)n_inst_total);
-            const int brc = device_build(c, pv.data(), nullptr, nullptr, n_inst_total, 0u, top.nodes8, top.depth8, rec.data(), nullptr, nullptr);
+            // (an instance in a hit leaf is ENTERED, a level switch of ~150 instructions, without a box test of its own:
+            // a leaf cost this high gives every instance a leaf to itself)
+            const int brc = device_build(c, pv.data(), nullptr, nullptr, n_inst_total, 0u, top.nodes8, top.depth8, rec.data(), nullptr, nullptr, 64.0f);
             if (brc) return brc;
             top.order.resize(n_inst_total);
             for (uint32_t sl = 0; sl < n_inst_total; ++sl) memcpy(&top.order[sl], &rec[12 * (size_t)sl + 3], 4);
@@ -1005,7 +1007,9 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         bi.depth8 = top.depth8 + max_blas_depth;
         bi.n_triangles = (uint32_t)slots;
         bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
-        if (gpu_any) bi.build_ms = (float)c->gpu_build_ms;  // world meshes + every placed mesh + the top level, device time
+        // world meshes + every placed mesh + the top level: device time, or the host builders' wall time
+        bi.build_ms = gpu_any ? (float)c->gpu_build_ms
+                              : (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     }
     c->scene_device_built = gpu_build || (gpu_any && s->n_instances != 0u);
     if (!c->has_device) {  // host-only context: BVH built, nothing to upload

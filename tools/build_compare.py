@@ -24,7 +24,11 @@ def main():
         r = prt.HipWavefrontRenderer(device=0, max_depth=depth)
         r.set_param("gpu_build", gpu_build)
         t0 = time.perf_counter()
-        r.Init(film, scene, cam)
+        try:
+            r.Init(film, scene, cam)
+        except prt.PrtError as e:
+            print(f"{args.config} gpu_build={gpu_build}: {e}", flush=True)
+            continue
         init_s = time.perf_counter() - t0
         info = r.bvh_info()
         r.set_samples_in_flight(args.spp)
