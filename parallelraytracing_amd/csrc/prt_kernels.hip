@@ -1461,6 +1461,63 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // triangles live in instance space (world-space meshes form one identity instance, which reproduces the
 // non-instanced results bit for bit); a candidate's key is its WORLD distance^2 |o - Mat * pos|^2 and its global
 // primitive index, as in the reference.  A lane changes level only when none of its items is left in the queue.
+// ---- the box tests of one 80-B node (w0..w4) against the lane's ray: expands to `eim` and `hitmask` --------------------
+// Quantized planes, children 0..3 (a) and 4..7 (b): w2 = {lox a, lox b, loy a, loy b}, w3 = {loz a, loz b, hix a, hix b},
+// w4 = {hiy a, hiy b, hiz a, hiz b}.  The near plane is the hi plane on an axis the ray travels along negatively; selected
+// with v_bfi_b32 under per-axis sign masks, not v_cndmask_b32 (the compiler puts some of the twelve selects on vcc; with
+// the bit selects the 5-wave instance needs no scratch).  The per-ray pad (2^-18 (|o|_1 + extent) in position space)
+// exceeds the rounding of the plane distances (a few 2^-24 of the same magnitude) by a factor > 10, so no relative slack
+// is needed on top of it.  Scalar FMAs: v_pk_fma_f32 measured 3.5 % slower here (12.95 -> 12.68 Grays/s on C3).
+#ifndef PRT_T8_BFI
+#define PRT_T8_BFI 1  // 0: v_cndmask_b32 selects (A/B builds: make EXTRA=-DPRT_T8_BFI=0)
+#endif
+#if PRT_T8_BFI
+#define T8_SEL(M, A, B) (((A) & (M)) | ((B) & ~(M)))
+#else
+#define T8_SEL(M, A, B) ((M) ? (A) : (B))
+#endif
+#define T8_CHILD(J, NX, FX, NY, FY, NZ, FZ)                                                                          \
+    {                                                                                                                \
+        const float tnx = __builtin_fmaf((float)(((NX) >> (8 * J)) & 0xFFu), Ax, Bnx);                               \
+        const float tny = __builtin_fmaf((float)(((NY) >> (8 * J)) & 0xFFu), Ay, Bny);                               \
+        const float tnz = __builtin_fmaf((float)(((NZ) >> (8 * J)) & 0xFFu), Az, Bnz);                               \
+        const float tfx = __builtin_fmaf((float)(((FX) >> (8 * J)) & 0xFFu), Ax, Bfx);                               \
+        const float tfy = __builtin_fmaf((float)(((FY) >> (8 * J)) & 0xFFu), Ay, Bfy);                               \
+        const float tfz = __builtin_fmaf((float)(((FZ) >> (8 * J)) & 0xFFu), Az, Bfz);                               \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));                     \
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlimit));                   \
+        const uint32_t cb = ((bits4 >> (8 * J)) & 0xFFu) << ((idx4 >> (8 * J)) & 0xFFu);                             \
+        hitmask |= (tn <= tf) ? cb : 0u;                                                                             \
+    }
+#define T8_HALF(META4, NX, FX, NY, FY, NZ, FZ)                                                                       \
+    {                                                                                                                \
+        const uint32_t meta4 = (META4);                                                                              \
+        const uint32_t in4 = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4; /* 1 in the bytes of internal children */  \
+        const uint32_t idx4 = (meta4 ^ (octinv4 & ((in4 << 3) - in4))) & 0x1F1F1F1Fu;                                \
+        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;                                                           \
+        T8_CHILD(0, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(1, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(2, NX, FX, NY, FY, NZ, FZ)                                                                          \
+        T8_CHILD(3, NX, FX, NY, FY, NZ, FZ)                                                                          \
+    }
+#define T8_BOXTEST()                                                                                                 \
+    const uint32_t eim = w0.w;                                                                                       \
+    const float Ax = __uint_as_float((eim & 0xFFu) << 23) * ix;                                                      \
+    const float Ay = __uint_as_float(((eim >> 8) & 0xFFu) << 23) * iy;                                               \
+    const float Az = __uint_as_float(((eim >> 16) & 0xFFu) << 23) * iz;                                              \
+    const float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);                  \
+    const float Bnx = __builtin_fmaf(px, ix, -anx), Bny = __builtin_fmaf(py, iy, -any), Bnz = __builtin_fmaf(pz, iz, -anz); \
+    const float Bfx = __builtin_fmaf(px, ix, -afx), Bfy = __builtin_fmaf(py, iy, -afy), Bfz = __builtin_fmaf(pz, iz, -afz); \
+    uint32_t mx = (uint32_t)((int32_t)__float_as_uint(ix) >> 31), my = (uint32_t)((int32_t)__float_as_uint(iy) >> 31), \
+             mz = (uint32_t)((int32_t)__float_as_uint(iz) >> 31);                                                    \
+    asm("" : "+v"(mx), "+v"(my), "+v"(mz)); /* opaque: keeps the and/or form from being folded back into selects */  \
+    const uint32_t nxa = T8_SEL(mx, w3.z, w2.x), nxb = T8_SEL(mx, w3.w, w2.y), fxa = T8_SEL(mx, w2.x, w3.z), fxb = T8_SEL(mx, w2.y, w3.w); \
+    const uint32_t nya = T8_SEL(my, w4.x, w2.z), nyb = T8_SEL(my, w4.y, w2.w), fya = T8_SEL(my, w2.z, w4.x), fyb = T8_SEL(my, w2.w, w4.y); \
+    const uint32_t nza = T8_SEL(mz, w4.z, w3.x), nzb = T8_SEL(mz, w4.w, w3.y), fza = T8_SEL(mz, w3.x, w4.z), fzb = T8_SEL(mz, w3.y, w4.w); \
+    uint32_t hitmask = 0u;                                                                                           \
+    T8_HALF(w1.z, nxa, fxa, nya, fya, nza, fza)                                                                      \
+    T8_HALF(w1.w, nxb, fxb, nyb, fyb, nzb, fzb)
+
 #define T8_SENTINEL 0xFFFFFFFFu
 template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false, bool PRIM = false>
 __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
@@ -1838,65 +1895,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[wv];
                 if ((uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
             }
-            const uint32_t eim = w0.w;
-            const float Ax = __uint_as_float((eim & 0xFFu) << 23) * ix;
-            const float Ay = __uint_as_float(((eim >> 8) & 0xFFu) << 23) * iy;
-            const float Az = __uint_as_float(((eim >> 16) & 0xFFu) << 23) * iz;
-            const float px = __uint_as_float(w0.x), py = __uint_as_float(w0.y), pz = __uint_as_float(w0.z);
-            const float Bnx = __builtin_fmaf(px, ix, -anx), Bny = __builtin_fmaf(py, iy, -any), Bnz = __builtin_fmaf(pz, iz, -anz);
-            const float Bfx = __builtin_fmaf(px, ix, -afx), Bfy = __builtin_fmaf(py, iy, -afy), Bfz = __builtin_fmaf(pz, iz, -afz);
-            // quantized planes, children 0..3 (a) and 4..7 (b): w2 = {lox a, lox b, loy a, loy b},
-            // w3 = {loz a, loz b, hix a, hix b}, w4 = {hiy a, hiy b, hiz a, hiz b}.  The near plane is the hi plane on an
-            // axis the ray travels along negatively.  Selected with v_bfi_b32 under per-axis sign masks, not v_cndmask_b32:
-            // the compiler puts some of these twelve selects on vcc, and a v_cndmask on vcc costs five times a plain
-            // VALU instruction on this chip (tools/issue_rate.hip, profiles/r2_issue_rate.txt)
-            uint32_t mx = (uint32_t)((int32_t)__float_as_uint(ix) >> 31), my = (uint32_t)((int32_t)__float_as_uint(iy) >> 31),
-                     mz = (uint32_t)((int32_t)__float_as_uint(iz) >> 31);
-            asm("" : "+v"(mx), "+v"(my), "+v"(mz));  // (opaque: keeps the and/or form below from being folded back into selects)
-#ifndef PRT_T8_BFI
-#define PRT_T8_BFI 1  // 0: v_cndmask_b32 selects (A/B builds: make EXTRA=-DPRT_T8_BFI=0)
-#endif
-#if PRT_T8_BFI
-#define T8_SEL(M, A, B) (((A) & (M)) | ((B) & ~(M)))
-#else
-#define T8_SEL(M, A, B) ((M) ? (A) : (B))
-#endif
-            const uint32_t nxa = T8_SEL(mx, w3.z, w2.x), nxb = T8_SEL(mx, w3.w, w2.y), fxa = T8_SEL(mx, w2.x, w3.z), fxb = T8_SEL(mx, w2.y, w3.w);
-            const uint32_t nya = T8_SEL(my, w4.x, w2.z), nyb = T8_SEL(my, w4.y, w2.w), fya = T8_SEL(my, w2.z, w4.x), fyb = T8_SEL(my, w2.w, w4.y);
-            const uint32_t nza = T8_SEL(mz, w4.z, w3.x), nzb = T8_SEL(mz, w4.w, w3.y), fza = T8_SEL(mz, w3.x, w4.z), fzb = T8_SEL(mz, w3.y, w4.w);
-#undef T8_SEL
-            uint32_t hitmask = 0u;
-            // The per-ray pad (2^-18 (|o|_1 + extent) in position space) exceeds the rounding of these plane distances
-            // (a few 2^-24 of the same magnitude) by a factor > 10, so no relative slack is needed on top of it.
-#define T8_CHILD(J, NX, FX, NY, FY, NZ, FZ)                                                                          \
-    {                                                                                                                \
-        /* scalar FMAs: v_pk_fma_f32 measured 3.5 % slower here (12.95 -> 12.68 Grays/s on C3) */                   \
-        const float tnx = __builtin_fmaf((float)(((NX) >> (8 * J)) & 0xFFu), Ax, Bnx);                               \
-        const float tny = __builtin_fmaf((float)(((NY) >> (8 * J)) & 0xFFu), Ay, Bny);                               \
-        const float tnz = __builtin_fmaf((float)(((NZ) >> (8 * J)) & 0xFFu), Az, Bnz);                               \
-        const float tfx = __builtin_fmaf((float)(((FX) >> (8 * J)) & 0xFFu), Ax, Bfx);                               \
-        const float tfy = __builtin_fmaf((float)(((FY) >> (8 * J)) & 0xFFu), Ay, Bfy);                               \
-        const float tfz = __builtin_fmaf((float)(((FZ) >> (8 * J)) & 0xFFu), Az, Bfz);                               \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));                     \
-        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlimit));                   \
-        const uint32_t cb = ((bits4 >> (8 * J)) & 0xFFu) << ((idx4 >> (8 * J)) & 0xFFu);                             \
-        hitmask |= (tn <= tf) ? cb : 0u;                                                                             \
-    }
-#define T8_HALF(META4, NX, FX, NY, FY, NZ, FZ)                                                                       \
-    {                                                                                                                \
-        const uint32_t meta4 = (META4);                                                                              \
-        const uint32_t in4 = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4; /* 1 in the bytes of internal children */  \
-        const uint32_t idx4 = (meta4 ^ (octinv4 & ((in4 << 3) - in4))) & 0x1F1F1F1Fu;                                \
-        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;                                                           \
-        T8_CHILD(0, NX, FX, NY, FY, NZ, FZ)                                                                          \
-        T8_CHILD(1, NX, FX, NY, FY, NZ, FZ)                                                                          \
-        T8_CHILD(2, NX, FX, NY, FY, NZ, FZ)                                                                          \
-        T8_CHILD(3, NX, FX, NY, FY, NZ, FZ)                                                                          \
-    }
-            T8_HALF(w1.z, nxa, fxa, nya, fya, nza, fza)
-            T8_HALF(w1.w, nxb, fxb, nyb, fyb, nzb, fzb)
-#undef T8_HALF
-#undef T8_CHILD
+            T8_BOXTEST()
             gx = w1.x;
             gy = (hitmask & 0xFF000000u) | (eim >> 24);
             const uint32_t tm = hitmask & 0x00FFFFFFu;
