@@ -105,6 +105,7 @@ struct PrtContext {
     int variant = 0;
     int abvh_enabled = 1;  // prt_set_param("prim_bvh", 0): keep the reference's linear scan over the analytic primitives
     int measure_spp = 1;  // samples of the instrumented batch of prt_measure_traversal
+    int node_stride = 0;      // prt_set_param("node_stride", 5 | 8): uint4 per 8-wide node slot, 0 = by tree size (upload_scene); before prt_set_scene
     int compact_primary = 1;  // prt_set_param("compact_primary", 0): k_raygen stores full ray records (A/B)
     int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
     PrtSampling sampling{0u, 0u, 0.0f};
@@ -397,6 +398,27 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
         c->d_tris = gb->d_tris;
         c->d_nrms = gb->d_nrms;
     }
+    // Node slots.  An 80-B node at a 16-B aligned address lies across two 128-B lines half of the time, so a visit that
+    // misses the caches moves 1.5 lines = 192 B (tools/gather_calib.hip).  Trees far beyond the L2s (C5: 1.6 M nodes =
+    // 131 MB, HBM-bound traversal) get one node per 128-B line instead: every miss is one line, at 1.6x the array size;
+    // trees the caches hold (C3: 16 MB) stay packed, where the smaller footprint is worth more than the line count.
+    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
+    const size_t n_nodes8 = gb ? (size_t)gb->n_nodes : n8.size() / 20;
+    c->dsc.node_stride = c->node_stride ? (uint32_t)c->node_stride : (n_nodes8 * 80 > ((size_t)64 << 20) ? 8u : 5u);
+    if (c->dsc.node_stride == 8u && n_nodes8) {
+        void* wide = nullptr;
+        HIPCHECK(c, hipMalloc(&wide, 128 * n_nodes8));
+        hipError_t e = hipMemset(wide, 0, 128 * n_nodes8);
+        if (e == hipSuccess)
+            e = gb ? hipMemcpy2D(wide, 128, c->d_nodes8, 80, 80, n_nodes8, hipMemcpyDeviceToDevice)
+                   : hipMemcpy2D(wide, 128, n8.data(), 80, 80, n_nodes8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(wide);
+            HIPCHECK(c, e);
+        }
+        free_dev(c->d_nodes8);
+        c->d_nodes8 = wide;
+    }
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
@@ -419,8 +441,7 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
         HIPCHECK(c, upload(&c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * 4));
         HIPCHECK(c, upload(&c->d_nodes4, c->bvh.nodes4.data(), c->bvh.nodes4.size() * 4));
     }
-    const std::vector<uint32_t>& n8 = c->nodes8_all.empty() ? c->bvh.nodes8 : c->nodes8_all;
-    if (!gb && !n8.empty()) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
+    if (!gb && !n8.empty() && c->dsc.node_stride != 8u) HIPCHECK(c, upload(&c->d_nodes8, n8.data(), n8.size() * 4));
     if (!c->abvh.nodes4.empty()) {
         HIPCHECK(c, upload(&c->d_abvh_nodes, c->abvh.nodes4.data(), c->abvh.nodes4.size() * 4));
         HIPCHECK(c, upload(&c->d_abvh_order, c->abvh.order.data(), c->abvh.order.size() * 4));
@@ -1504,6 +1525,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
     else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
     else if (n == "compact_primary" && (value == 0 || value == 1)) c->compact_primary = value;
+    else if (n == "node_stride" && (value == 0 || value == 5 || value == 8)) c->node_stride = value;
     else if (n == "tail" && value >= 0 && value <= 64) c->tune.tail = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;

@@ -53,6 +53,7 @@ struct DevScene {
     const DevInstance* insts;   // placed mesh copies; with n_insts > 0 nodes8 starts with a top-level tree over them
     const uint32_t* tlas_inst;  // top-level leaf slot -> instance index
     uint32_t n_insts;
+    uint32_t node_stride;       // uint4 per 8-wide node slot: 5 (packed, 80 B) or 8 (one node per 128-B line: big trees, see upload_scene)
     uint32_t depth8;            // levels of the 8-wide tree (two-level scenes: top level + deepest mesh tree)
     uint32_t n_prims;
     uint32_t n_nodes;

@@ -1886,7 +1886,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             sp += (cy > 0x00FFFFFFu) ? 1 : 0;
             const uint32_t slot = (bit - 24u) ^ (octinv4 & 7u);
             const uint32_t idx = cx + (uint32_t)__popc(cy & ((1u << slot) - 1u));  // bits 0..7 of cy: imask
-            const uint4* nb = sc.nodes8 + 5 * (size_t)idx;
+            const uint4* nb = sc.nodes8 + (size_t)sc.node_stride * idx;
             const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
             if (STATS) {
                 ++n_nodes;

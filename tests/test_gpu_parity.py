@@ -643,6 +643,35 @@ def test_device_built_two_level_tree_gives_the_same_hits_and_image(with_world_me
     assert np.array_equal(films[0][0], acc) and films[0][1] == rays
 
 
+@pytest.mark.parametrize("gpu_build", [0, 1])
+def test_one_node_per_cache_line_layout_gives_the_same_hits_and_image(gpu_build):
+    """prt_set_param("node_stride", 8): the 8-wide nodes in 128-B slots (what upload_scene picks by itself for trees far
+    beyond the L2s, e.g. config C5) instead of packed 80-B records: same closest hits as the oracle's brute force, same
+    image as the packed layout, for host-built and device-built trees and for a scene with placed copies."""
+    mesh = prt.scenes.refined("bunny.ply", 12_000)
+    W, H, spp, depth = 128, 72, 2, 5
+    for scene, cam in ((prt.scenes.mesh_scene(mesh), prt.Camera(position=(1.5, 1.0, 2.5), width=W, height=H)),
+                       (_instanced_scene(mesh, True), prt.Camera(position=(6.0, 4.0, 9.0), width=W, height=H))):
+        films = []
+        for stride in (8, 5):
+            r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=5)
+            r.set_param("gpu_build", gpu_build)
+            r.set_param("node_stride", stride)
+            film = prt.Film(W, H)
+            r.Init(film, scene, cam)
+            if stride == 8:
+                rng = np.random.default_rng(29)
+                o, d = util.random_rays(rng, 3000, center=(0, 0.5, 0), radius=9.0, spread=4.0)
+                got = r.closest_hit(o, d)
+                want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
+                assert util.hits_equal(got, want) == []
+            r.ProgressiveRender(spp)
+            r.download()
+            films.append((film.accum.copy(), r.stats().rays_total))
+        assert np.array_equal(films[0][0], films[1][0]) and films[0][1] == films[1][1]
+        assert films[0][0].sum() > 0
+
+
 def test_kernel_occupancy_report():
     """prt_kernel_occupancy: the static wavefront occupancy bench.py reports next to the roofline."""
     scene = prt.scenes.mesh_scene(prt.Mesh(prt.scenes.asset("bunny.ply")))
