@@ -40,7 +40,9 @@ PRT_DEV uint32_t xcd_remap(uint32_t b, uint32_t n) {
 #define CNT_B(c, d) (c)[(d) * CNT_STRIDE + 32u]
 #define CNT_C(c, d) (c)[(d) * CNT_STRIDE + 16u]
 #define PRODUCER_BLOCK 1024  // k_raygen
+#ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512      // k_shade: its variants with 82 SGPRs / 78 VGPRs keep 6 waves per SIMD this way (1024: 4)
+#endif
 
 // Slot reservation for a BLOCK-thread block with ONE atomic per side (a counter word sustains only ~88
 // returning atomics/us, MI355X_MICROARCH.md "dequeue"; the per-wave form — the wave64 equivalent of the
@@ -95,6 +97,50 @@ PRT_DEV uint32_t block_alloc2(bool front, bool back, bool done, uint32_t* cntA, 
         if (base) *base = s_base_b;
     }
     return slot;
+}
+
+// The same reservation for K rays per thread with ONE atomic per side per block (k_raygen with jittered primary rays:
+// a counter word executes ~87 returning atomics per microsecond whatever the block size, tools/atomic_rate.hip, so a
+// kernel cannot retire more than 87 reserving blocks per microsecond; K rays per reservation divide that floor and the
+// two barriers by K).  Within a wave ray k of every lane comes before ray k + 1.  Same contract as block_alloc2.
+template <int BLOCK, int K>
+PRT_DEV void block_alloc2k(const bool (&front)[K], const bool (&back)[K], uint32_t* cntA, uint32_t* cntB, uint32_t cap,
+                           uint32_t (&slot)[K]) {
+    __shared__ uint32_t s_a[BLOCK / 64], s_b[BLOCK / 64];
+    __shared__ uint32_t s_base_a, s_base_b;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t ja[K], jb[K], na = 0, nb = 0;  // offsets of the lane's rays within the wave's reservation
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long ma = __ballot(front[k]), mb = __ballot(back[k]);
+        ja[k] = na + (uint32_t)__popcll(ma & below);
+        jb[k] = nb + (uint32_t)__popcll(mb & below);
+        na += (uint32_t)__popcll(ma);
+        nb += (uint32_t)__popcll(mb);
+    }
+    if (lane == 0) {
+        s_a[wave] = na;
+        s_b[wave] = nb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tb = 0;
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+            ta += s_a[w];
+            tb += s_b[w];
+        }
+        s_base_a = ta ? atomicAdd(cntA, ta) : 0u;
+        s_base_b = tb ? atomicAdd(cntB, tb) : 0u;
+    }
+    __syncthreads();
+    uint32_t wa = s_base_a, wb = s_base_b;
+    for (uint32_t w = 0; w < wave; ++w) {
+        wa += s_a[w];
+        wb += s_b[w];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) slot[k] = front[k] ? wa + ja[k] : back[k] ? cap - 1u - (wb + jb[k]) : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -224,6 +270,9 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 // computes the camera ray and its classification once and emits it for RAYGEN_GROUP samples, each with its own RNG
 // seed and path id; every sample's primary ray is still traced on its own by the traversal kernel.
 #define RAYGEN_GROUP 8
+#ifndef RAYGEN_ALLOC
+#define RAYGEN_ALLOC 4  // jittered rays per slot reservation (divides RAYGEN_GROUP)
+#endif
 #define RAYGEN_GROUP_NOJITTER 64u  // without jitter: one wave's worth of samples per pixel and block (pixel-major slots)
 // SAMPLING = false compiles the Russian-roulette / clamp code out: with it in, k_shade needs 82 instead of 74 SGPRs,
 // which costs a wave per SIMD, i.e. with 1024-thread blocks one of the two blocks per CU (measured: shade 50 % slower).
@@ -354,37 +403,60 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         }
         return;
     }
-    for (uint32_t sl = s0; sl < s1; ++sl) {  // block-uniform trip count
-        const uint32_t i = sl * tm.n_pix_local + pl;  // path id
-        f3 o = o0, d = d0, thr = mk3(1.f, 1.f, 1.f);
-        uint32_t rng = 0, depth = 0, id0 = id00;
-        float d2_0 = d2_00;
-        bool front = false, back = false;
-        if (valid) {
-            rng = path_seed(pixel, first_sample + sl, seed);
-            {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
-                const float u1 = rnd01(rng);
-                const float u2 = rnd01(rng);
-                camera_ray(cam, (float)px + u1, (float)py + u2, o, d);
-                front = classify_ray<ABVH, PRODUCER_BLOCK>(sc, o, d, id0, d2_0);
+    // Jittered primary rays, RAYGEN_ALLOC samples of the pixel per slot reservation.  What is stored per ray is its
+    // direction, RNG state and the analytic scan's result: with no shading budget advance_path never scatters, so the origin
+    // stays the camera position, the throughput 1 and the segment index 0 (paths that end right here write rad[] inside).
+    constexpr int KA = ABVH ? 2 : RAYGEN_ALLOC;  // (the primitive-BVH walk needs the registers: 4 rays would spill)
+    for (uint32_t sl = s0; sl < s1; sl += KA) {  // block-uniform trip count
+        f3 dk[KA];
+        uint32_t rngk[KA], idk[KA], slotk[KA];
+        float d2k[KA];
+        bool frontk[KA], backk[KA];
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+            const uint32_t sk = sl + (uint32_t)kk;
+            const uint32_t i = sk * tm.n_pix_local + pl;  // path id
+            f3 o = o0, d = d0, thr = mk3(1.f, 1.f, 1.f);
+            uint32_t rng = 0, depth = 0, id0 = id00;
+            float d2_0 = d2_00;
+            bool front = false, back = false;
+            if (sk < s1 && valid) {
+                rng = path_seed(pixel, first_sample + sk, seed);
+                {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
+                    const float u1 = rnd01(rng);
+                    const float u2 = rnd01(rng);
+                    camera_ray(cam, (float)px + u1, (float)py + u2, o, d);
+                    front = classify_ray<ABVH, PRODUCER_BLOCK>(sc, o, d, id0, d2_0);
+                }
+                if (!front) {
+                    const int r = advance_path<0, false, ABVH, PRODUCER_BLOCK>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
+                    front = r == 1;
+                    back = r == 2;
+                }
+            } else if (sk < s1 && in_range) {
+                rad[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // partial tiles outside the image: no path
             }
-            if (!front) {
-                const int r = advance_path<0, false, ABVH, PRODUCER_BLOCK>(sc, id0, o, d, thr, rng, depth, max_depth, sp, &rad[i], id0, d2_0);
-                front = r == 1;
-                back = r == 2;
+            dk[kk] = d;
+            rngk[kk] = rng;
+            idk[kk] = id0;
+            d2k[kk] = d2_0;
+            frontk[kk] = front;
+            backk[kk] = back;
+        }
+        block_alloc2k<PRODUCER_BLOCK, KA>(frontk, backk, &CNT_A(counts, 0), &CNT_B(counts, 0), n_paths, slotk);
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+            const uint32_t slot = slotk[kk];
+            if (slot != 0xFFFFFFFFu) {
+                const uint32_t i = (sl + (uint32_t)kk) * tm.n_pix_local + pl;
+                ro[slot] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, __uint_as_float(i));
+                rd[slot] = make_float4(dk[kk].x, dk[kk].y, dk[kk].z, __uint_as_float(rngk[kk]));
+                rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+                hit[slot] = idk[kk];
+                hd2[slot] = d2k[kk];
             }
-        } else if (in_range) {
-            rad[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // partial tiles outside the image: no path
         }
-        const uint32_t slot = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0), &CNT_C(counts, 0), n_paths);
-        if (slot != 0xFFFFFFFFu) {
-            ro[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-            rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-            rt[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(depth));
-            hit[slot] = id0;
-            hd2[slot] = d2_0;
-        }
-        __syncthreads();  // block_alloc2's LDS counts are reused by the next trip (see its contract)
+        __syncthreads();  // block_alloc2k's LDS counts are reused by the next trip (see block_alloc2's contract)
     }
 }
 
