@@ -1711,6 +1711,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     k = 0xFFFFFFFFu;
                 } else if (!STEAL || ((helped >> lane) & 1ull) == 0ull) {
                     hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
+#ifdef PRT_PROBE_REBOUND  // diagnostic build: leave the final distance where the next launch takes its initial bound from
+                    ((float*)hd2)[k] = LEAN ? __uint_as_float((uint32_t)(((volatile unsigned long long*)s_key)[tid] >> 32)) : best.d2;
+#endif
                     k = 0xFFFFFFFFu;
                 }
             }
@@ -2450,6 +2453,15 @@ bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune) {
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
                          const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary) {
+#ifdef PRT_PROBE_REBOUND
+    // diagnostic build (tools/bounce_stats.py --rebound): the instrumented launch is preceded by a plain one that leaves
+    // every ray's FINAL hit distance as its initial culling bound, so the instrumented walk's visit counts are those of a
+    // traversal that knew the answer from the start: the floor for any visiting order / triangle-test schedule
+    if (stats) {
+        prt_launch_traverse(st, sc, in, count_ptr, work, spill, max_rays, tree_depth, stack4, tune, nullptr, primary);
+        hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
+    }
+#endif
     uint32_t g = tune.grid_blocks;
     const uint32_t need_blocks = blocks_for(max_rays);
     if (g > need_blocks) g = need_blocks;
