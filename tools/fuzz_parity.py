@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Randomized parity: random scenes (analytic primitives of every material, refined meshes, placed copies), random cameras,
+builders, kernel tunables and sampling flags; every frame bit for bit against the oracle (throughput form) + ray counts.
+  python tools/fuzz_parity.py --cases 200 --seed 1      (GPU box; ~0.3 s per case)
+Uses the oracle, i.e. test infrastructure: this is a checker, not a product path."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import parallelraytracing_amd as prt  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+MESHES = {}
+
+
+def mesh(name, tris):
+    key = (name, tris)
+    if key not in MESHES:
+        m = prt.Mesh(prt.scenes.asset(name))
+        MESHES[key] = m.refine(tris) if tris else m
+    return MESHES[key]
+
+
+def random_scene(rng):
+    sc = prt.Scene(preset=None)
+    mats = [sc.AddLambertian(tuple(rng.uniform(0.2, 0.9, 3))), sc.AddLambertian(tuple(rng.uniform(0.2, 0.9, 3))),
+            sc.AddMetal(tuple(rng.uniform(0.5, 1.0, 3)), float(rng.choice([0.0, 0.05, 0.3]))),
+            sc.AddDielectric(float(rng.choice([1.3, 1.5, 2.4]))), sc.AddEmissive(tuple(rng.uniform(2, 12, 3)))]
+    pick = lambda: mats[int(rng.integers(0, len(mats)))]  # noqa: E731
+    desc = []
+    if rng.random() < 0.8:
+        sc.AddQuad(float(rng.uniform(8, 40)), float(rng.uniform(8, 40)), mats[0], translation=(0.0, float(rng.uniform(-2.0, -0.5)), 0.0))
+    if rng.random() < 0.7:
+        sc.AddQuad(3.0, 3.0, mats[4], euler_deg=(180.0, 0.0, 0.0), translation=(float(rng.uniform(-2, 2)), float(rng.uniform(4, 8)), float(rng.uniform(-2, 2))))
+    n_prims = int(rng.choice([0, 1, 3, 8, 20, 40]))
+    for _ in range(n_prims):
+        tr = tuple(float(v) for v in rng.uniform(-5, 5, 3))
+        if rng.random() < 0.6:
+            s = float(rng.uniform(0.3, 1.5))
+            sc.AddCircle(float(rng.uniform(0.2, 1.2)), pick(), scale=(s, s, s), translation=tr)
+        else:
+            sc.AddQuad(float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3)), pick(),
+                       euler_deg=(float(rng.choice([0, 50, 90, 180])), 0.0, 0.0), translation=tr)
+    desc.append(f"{n_prims} prims")
+    kind = rng.choice(["none", "world", "inst", "both"], p=[0.1, 0.4, 0.25, 0.25])
+    name, tris = [("icosahedron.ply", 0), ("icosahedron.ply", 300), ("bunny.ply", 0), ("bunny.ply", 4000), ("hand.ply", 0),
+                  ("dragon.ply", 0)][int(rng.integers(0, 6))]
+    if kind in ("world", "both"):
+        sc.AddMesh(mesh(name, tris), pick())
+        desc.append(f"world {name}:{tris}")
+    if kind in ("inst", "both"):
+        n_inst = int(rng.integers(1, 7))
+        name2, tris2 = [("icosahedron.ply", 0), ("bunny.ply", 0), ("icosahedron.ply", 1200)][int(rng.integers(0, 3))]
+        for _ in range(n_inst):
+            sc.AddInstance(mesh(name2, tris2), pick(), scale=float(rng.uniform(0.3, 2.5)),
+                           euler_deg=tuple(float(v) for v in rng.uniform(-180, 180, 3)),
+                           translation=tuple(float(v) for v in rng.uniform(-5, 5, 3)))
+        desc.append(f"{n_inst} copies of {name2}:{tris2}")
+    return sc, ", ".join(desc), kind
+
+
+def run_case(case, seed):
+    rng = np.random.default_rng([seed, case])
+    scene, desc, kind = random_scene(rng)
+    W, H = int(rng.choice([17, 64, 96, 131])), int(rng.choice([9, 48, 72]))
+    pos = rng.normal(size=3)
+    pos = pos / np.linalg.norm(pos) * rng.uniform(3, 14)
+    pos[1] = abs(pos[1]) + 0.3
+    front = -pos + rng.uniform(-1, 1, 3)
+    cam = prt.Camera(position=tuple(float(v) for v in pos), front=tuple(float(v) for v in front), width=W, height=H)
+    depth = int(rng.integers(1, 9))
+    spp = int(rng.integers(1, 4))
+    rseed = int(rng.integers(0, 1 << 30))
+    r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=rseed)
+    params = {}
+    has_mesh = kind != "none"
+    if has_mesh and rng.random() < 0.5:
+        params["gpu_build"] = int(rng.choice([1, 2]))
+    if rng.random() < 0.3:
+        params["node_stride"] = 8
+    if rng.random() < 0.3:
+        params["prim_bvh"] = 0
+    if rng.random() < 0.3:
+        params["compact_primary"] = 0
+    if rng.random() < 0.3:
+        params["fuse"] = int(rng.integers(0, 2))
+    if rng.random() < 0.2:
+        params["exact_grids"] = int(rng.integers(0, 3))
+    if rng.random() < 0.2 and kind in ("world",):
+        params["stack_cap"] = int(rng.integers(2, 6))  # forces the overflow list (host-built trees only: needs the 4-wide tree)
+        params.pop("gpu_build", None)
+    if rng.random() < 0.2:
+        params["refill_min"] = int(rng.choice([1, 8, 32, 64]))
+    if rng.random() < 0.2:
+        params["tri_min"] = int(rng.choice([1, 8, 64]))
+    for k, v in params.items():
+        r.set_param(k, v)
+    film = prt.Film(W, H)
+    try:
+        r.Init(film, scene, cam)
+    except prt.PrtError as e:  # e.g. a tree too deep for the two-level kernel: must be a clean error
+        return f"case {case}: Init refused ({str(e)[:80]}) [{desc}]", True
+    sp = None
+    if rng.random() < 0.4:
+        sp = r.set_sampling(jitter=int(rng.integers(0, 2)), rr_depth=int(rng.choice([0, 1, 3])), clamp=float(rng.choice([0.0, 1.5])))
+    sif = int(rng.integers(1, spp + 1))
+    r.set_samples_in_flight(sif)
+    r.ProgressiveRender(spp)
+    r.download()
+    osc = orc.OracleScene(scene.desc())
+    acc, wts, rays = osc.render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=rseed, iterative=True, use_bvh=True, n_threads=8, sampling=sp)
+    st = r.stats()
+    nbad = int((film.accum != acc).any(axis=-1).sum())
+    ok = nbad == 0 and np.array_equal(film.weights, wts) and st.rays_total == rays
+    msg = (f"case {case}: {'ok ' if ok else 'MISMATCH'} {W}x{H} spp {spp} depth {depth} [{desc}] params {params} sampling "
+           f"{(sp.jitter, sp.rr_depth, sp.clamp) if sp else None}: {nbad} bad pixels, rays {st.rays_total} vs {rays}")
+    return msg, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    t0 = time.time()
+    bad = 0
+    for case in range(a.first, a.first + a.cases):
+        msg, ok = run_case(case, a.seed)
+        if not ok:
+            bad += 1
+        if a.verbose or not ok or "refused" in msg:
+            print(msg, flush=True)
+        if (case - a.first) % 25 == 24:
+            print(f"... {case - a.first + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_parity: {a.cases} cases from {a.first} (seed {a.seed}): {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
