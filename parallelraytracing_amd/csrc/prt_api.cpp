@@ -758,6 +758,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     // not keeps the linear scan for the whole scene. ----
     c->abvh = BvhBuild();
     float extent_prims = 0.0f;
+    double quad_pad[3] = {0.0, 0.0, 0.0};
     if (c->abvh_enabled && n_prims > 16u) {
         std::vector<float> pv(9 * (size_t)n_prims);
         bool ok = true;
@@ -780,6 +781,14 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
                 for (int a = 0; a < 3; ++a) {
                     mn[a] = (float)((double)M[12 + a] - R);
                     mx[a] = (float)((double)M[12 + a] + R);
+                }
+                // phantom hits of the fp32 discriminant: up to K * dist^2 / R outside the sphere, dist <= |o|_1 + |c|_1
+                // (K = 1e-6: measured worst 2.0e-7 over 3.6e7 grazing rays at 3..1000 units, analytic bound 4.8e-7)
+                if (R > 0.0) {
+                    const double q = 1e-6 / R, c1 = std::fabs((double)M[12]) + std::fabs((double)M[13]) + std::fabs((double)M[14]);
+                    quad_pad[0] = std::max(quad_pad[0], q);
+                    quad_pad[1] = std::max(quad_pad[1], 2.0 * q * c1);
+                    quad_pad[2] = std::max(quad_pad[2], q * c1 * c1);
                 }
             } else {  // quad in the local plane y = 0
                 for (int corner = 0; corner < 4; ++corner) {
@@ -810,6 +819,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     if (!c->abvh.nodes4.empty()) {
         extent = std::max(extent, extent_prims);  // the culling pad of the primitive walk scales with the scene
         d.extent = extent;
+        for (int k = 0; k < 3; ++k) d.abvh_q[k] = (float)(quad_pad[k] * 1.0000002);  // (rounded up)
     }
 
     // ---- placed mesh copies (PrtInstance): one tree per instanced mesh in its own space + a top-level tree over the

@@ -59,6 +59,10 @@ struct DevScene {
     uint32_t n_nodes;
     uint32_t n_tris;
     float pad;     // culling pad coefficient (2^-18): pad_ray = pad * (|o|_1 + extent)
+    // primitive walk only: + (abvh_q[0] * A + abvh_q[1]) * A + abvh_q[2] with A = |o|_1, an upper envelope of
+    // K / R_i * (A + |c_i|_1)^2 over the scene's spheres (world radius R_i, centre c_i): how far OUTSIDE a sphere a ray may
+    // pass and still be a hit in the reference's fp32 arithmetic (see prt_set_scene)
+    float abvh_q[3];
     float extent;  // max |coordinate| of any mesh vertex
     float root_min[3], root_max[3];  // bounds of all triangles (BVH root box)
     float sky[3];

@@ -500,7 +500,12 @@ PRT_DEV void scan_analytic(const DevScene& sc, f3 o, f3 d, Closest& best, uint32
         return;
     }
     const f3 ld = normalize3(d);
-    const float pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+    // The per-ray pad has a term that grows with the SQUARE of the distance: Circle::Intersect's discriminant
+    // b*b - 4*a*c (shape.h:160-163) cancels catastrophically for a far origin, so a ray that passes up to
+    // ~2e-7 * dist^2 / R outside a sphere can still be a hit of the reference's arithmetic (measured; 4.8e-7 is the
+    // worst-case bound), which a world box padded in proportion to the distance alone would cull.
+    const float A1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
+    const float pad = sc.pad * (A1 + sc.extent) + ((sc.abvh_q[0] * A1 + sc.abvh_q[1]) * A1 + sc.abvh_q[2]);
     const float ix = 1.0f / (__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
     const float iy = 1.0f / (__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
     const float iz = 1.0f / (__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);

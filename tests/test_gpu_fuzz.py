@@ -28,3 +28,61 @@ def test_random_scenes_cameras_builders_and_tunables_bit_exact(first):
         if not ok:
             bad.append(msg)
     assert bad == []
+
+
+@pytest.mark.parametrize("first", [0, 40])
+def test_awkward_rays_against_the_brute_force_scan(first):
+    """Closest hit of rays with zero direction components, axis-parallel rays, lattice origins, grazing and far-away rays on
+    random scenes / builders / layouts, against the oracle's linear scan (PrimitiveList::Intersect, primitive.cpp:21-59)."""
+    bad = []
+    for case in range(first, first + 40):
+        msg, ok = fuzz.run_ray_case(case, seed=11, n=2048)
+        if not ok:
+            bad.append(msg)
+    assert bad == []
+
+
+def test_grazing_rays_from_far_away_keep_the_reference_spheres_phantom_hits():
+    """Circle::Intersect's discriminant b*b - 4*a*c (shape.h:160-163) cancels for a far origin: a ray that passes up to
+    ~2e-7 * dist^2 / R OUTSIDE a sphere is still a hit of the reference's arithmetic.  The walk over the primitives' world
+    boxes (scenes with more than 16 primitives) must not cull those: its pad has a term in dist^2 (DevScene::abvh_q).
+    40 small spheres, 200 k rays aimed to graze them within a few of those margins from 30 ... 1000 units away, against
+    the oracle's linear scan; the test requires that phantom hits do occur in the sample."""
+    import numpy as np
+    from util import prt
+    rng = np.random.default_rng(5)
+    sc = prt.Scene(preset=None)
+    mat = sc.AddLambertian((0.7, 0.7, 0.7))
+    centres, radii = [], []
+    for _ in range(40):
+        c = rng.uniform(-5, 5, 3)
+        s = float(rng.uniform(0.3, 1.5))
+        r = float(rng.uniform(0.1, 0.6))
+        sc.AddCircle(r, mat, scale=(s, s, s), translation=tuple(float(v) for v in c))
+        centres.append(c)
+        radii.append(r * s)
+    centres, radii = np.array(centres), np.array(radii)
+    n = 200_000
+    i = rng.integers(0, 40, n)
+    dist = np.exp(rng.uniform(np.log(30.0), np.log(1000.0), n))
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3))
+    v -= (v * u).sum(1, keepdims=True) * u
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    m = rng.uniform(-2e-7, 5e-7, n) * dist * dist / radii[i]      # signed distance of the line from the sphere's surface
+    ang = np.arcsin(np.clip((radii[i] + m) / dist, 0.0, 1.0))
+    o = (centres[i] + u * dist[:, None]).astype(np.float32)
+    d = (-u * np.cos(ang)[:, None] + v * np.sin(ang)[:, None]).astype(np.float32)
+    d = np.stack([prt.glm_normalize(x) for x in d]).astype(np.float32)
+    r = prt.HipWavefrontRenderer(device=0, max_depth=2, seed=0)
+    r.Init(prt.Film(16, 16), sc, prt.Camera(position=(5.0, 5.0, 8.0), width=16, height=16))
+    got = r.closest_hit(o, d)
+    want = util.oracle_scene(sc).closest_hit(o, d, use_bvh=False, n_threads=16)
+    assert util.hits_equal(got, want) == []
+    # phantom hits are in the sample: hits on the aimed-at sphere by rays whose line (as fp32 data, in double) misses it
+    oo, dd = o.astype(np.float64), d.astype(np.float64)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    miss_by = np.linalg.norm(np.cross(oo - centres[i], dd), axis=1) - radii[i]
+    phantom = (want["prim"] == i) & (miss_by > 1e-6 * dist)
+    assert phantom.sum() > 100, int(phantom.sum())

@@ -37,8 +37,8 @@ def hits_equal(a, b):
     for f in ("prim", "front_face", "material_id"):
         if not np.array_equal(a[f], b[f]):
             bad.append(f)
-    for f in ("d2", "position", "normal"):
-        if not np.array_equal(a[f], b[f]):
+    for f in ("d2", "position", "normal"):  # (a NaN on both sides is agreement: e.g. normalize(0) for a sphere hit
+        if not np.all((a[f] == b[f]) | (np.isnan(a[f]) & np.isnan(b[f]))):  # reported at its very centre from far away)
             bad.append(f)
     return bad
 

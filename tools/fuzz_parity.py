@@ -50,8 +50,10 @@ def random_scene(rng):
     kind = rng.choice(["none", "world", "inst", "both"], p=[0.1, 0.4, 0.25, 0.25])
     name, tris = [("icosahedron.ply", 0), ("icosahedron.ply", 300), ("bunny.ply", 0), ("bunny.ply", 4000), ("hand.ply", 0),
                   ("dragon.ply", 0)][int(rng.integers(0, 6))]
+    world = None
     if kind in ("world", "both"):
-        sc.AddMesh(mesh(name, tris), pick())
+        world = mesh(name, tris)
+        sc.AddMesh(world, pick())
         desc.append(f"world {name}:{tris}")
     if kind in ("inst", "both"):
         n_inst = int(rng.integers(1, 7))
@@ -61,12 +63,12 @@ def random_scene(rng):
                            euler_deg=tuple(float(v) for v in rng.uniform(-180, 180, 3)),
                            translation=tuple(float(v) for v in rng.uniform(-5, 5, 3)))
         desc.append(f"{n_inst} copies of {name2}:{tris2}")
-    return sc, ", ".join(desc), kind
+    return sc, ", ".join(desc), kind, world
 
 
 def run_case(case, seed):
     rng = np.random.default_rng([seed, case])
-    scene, desc, kind = random_scene(rng)
+    scene, desc, kind, _ = random_scene(rng)
     W, H = int(rng.choice([17, 64, 96, 131])), int(rng.choice([9, 48, 72]))
     pos = rng.normal(size=3)
     pos = pos / np.linalg.norm(pos) * rng.uniform(3, 14)
@@ -122,17 +124,73 @@ def run_case(case, seed):
     return msg, ok
 
 
+def run_ray_case(case, seed, n=4096):
+    """Closest hit of awkward rays against the oracle's BRUTE-FORCE scan: directions with zero components (infinite slab
+    reciprocals), axis-parallel rays inside box planes, origins on vertices / inside the mesh / far away, near-degenerate
+    directions; a random scene and builder as above."""
+    rng = np.random.default_rng([seed, case, 77])
+    scene, desc, kind, world = random_scene(rng)
+    r = prt.HipWavefrontRenderer(device=0, max_depth=2, seed=0)
+    params = {}
+    if kind != "none" and rng.random() < 0.5:
+        params["gpu_build"] = int(rng.choice([1, 2]))
+    if rng.random() < 0.3:
+        params["node_stride"] = 8
+    if rng.random() < 0.3:
+        params["prim_bvh"] = 0
+    for k, v in params.items():
+        r.set_param(k, v)
+    film = prt.Film(16, 16)
+    r.Init(film, scene, prt.Camera(position=(5.0, 5.0, 8.0), width=16, height=16))
+    o = rng.uniform(-6, 6, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    q = n // 8
+    d[0:q, int(rng.integers(0, 3))] = 0.0                      # one zero component
+    ax = int(rng.integers(0, 3))
+    d[q:2 * q] = 0.0
+    d[q:2 * q, ax] = rng.choice([-1.0, 1.0], size=q)           # axis-parallel
+    o[2 * q:3 * q] = np.round(o[2 * q:3 * q] * 2) / 2           # origins on a coarse lattice (often on box planes / quads)
+    d[3 * q:4 * q] *= np.float32(1e-3)                          # short direction vectors (normalised below like any other)
+    d[4 * q:5 * q, 1] = rng.choice([1e-9, -1e-9, 1e-7], size=q).astype(np.float32)  # grazing the y = const quads
+    o[5 * q:6 * q] *= np.float32(50.0)                          # far away, aimed at the origin
+    d[5 * q:6 * q] = -o[5 * q:6 * q] + rng.normal(size=(q, 3)).astype(np.float32)
+    verts = world.GetVertices() if world is not None else None
+    if verts is not None and len(verts):
+        sel = verts[rng.integers(0, len(verts), size=q)]
+        d[6 * q:7 * q] = sel - o[6 * q:7 * q]                   # aimed exactly at mesh vertices (if the mesh is in the scene)
+    d = np.stack([prt.glm_normalize(v) if np.any(v != 0) else np.array([0, 0, 1], np.float32) for v in d]).astype(np.float32)
+    got = r.closest_hit(o, d)
+    want = orc.OracleScene(scene.desc()).closest_hit(o, d, use_bvh=False, n_threads=8)
+    bad = []
+    for f in ("prim", "front_face", "material_id", "d2", "position", "normal"):
+        same = got[f] == want[f]
+        if got[f].dtype.kind == "f":
+            same = same | (np.isnan(got[f]) & np.isnan(want[f]))
+        if not np.all(same):
+            bad.append(f)
+    ok = bad == []
+    if not ok:
+        idx = np.nonzero((got["prim"] != want["prim"]) | (got["d2"] != want["d2"]))[0]
+        for i in idx[:6]:
+            print(f"   ray {i}: o {o[i].tolist()} d {d[i].tolist()} got prim {got['prim'][i]} d2 {got['d2'][i]!r} front {got['front_face'][i]} "
+                  f"want prim {want['prim'][i]} d2 {want['d2'][i]!r} front {want['front_face'][i]}", flush=True)
+        print(f"   {len(idx)} rays differ; n_prims {len(scene.primitives)}", flush=True)
+    nhit = int((got["prim"] != 0xFFFFFFFF).sum()) if got["prim"].dtype.kind == "u" else int((got["prim"] >= 0).sum())
+    return f"ray case {case}: {'ok ' if ok else 'MISMATCH ' + str(bad)} [{desc}] params {params}: {nhit} of {n} hit", ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--rays", action="store_true", help="closest-hit cases with awkward rays against the brute-force scan")
     a = ap.parse_args()
     t0 = time.time()
     bad = 0
     for case in range(a.first, a.first + a.cases):
-        msg, ok = run_case(case, a.seed)
+        msg, ok = run_ray_case(case, a.seed) if a.rays else run_case(case, a.seed)
         if not ok:
             bad += 1
         if a.verbose or not ok or "refused" in msg:
