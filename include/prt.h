@@ -305,7 +305,8 @@ int prt_set_variant(PrtContext* ctx, int variant);
  * (test hook), "gpu_build" (the next prt_set_scene builds the 8-wide tree(s) on the device, placed copies and the top level
  * included: 1 = PLOC + SAH top + optimal collapse, ~20 ms for 870 k triangles, traverses within 2-3 % of the host tree;
  * 2 = Morton octree, ~3 ms, ~20 % slower to traverse), "node_stride" (before prt_set_scene: 5 = 8-wide nodes packed at
- * 80 B, 8 = one node per 128-B line, 0 = by tree size, default).  Results never depend on a tunable.  Unknown names / bad values
+ * 80 B, 8 = one node per 128-B line, 0 = by tree size, default), "pad_log2" (before prt_set_scene: the culling pad is 2^-n of
+ * the coordinates' magnitude, default 18; A/B only).  Results never depend on a tunable.  Unknown names / bad values
  * return PRT_ERR_INVALID. */
 int prt_set_param(PrtContext* ctx, const char* name, int value);
 

@@ -105,6 +105,7 @@ struct PrtContext {
     int variant = 0;
     int abvh_enabled = 1;  // prt_set_param("prim_bvh", 0): keep the reference's linear scan over the analytic primitives
     int measure_spp = 1;  // samples of the instrumented batch of prt_measure_traversal
+    float pad_coeff = kPadCoeff;  // prt_set_param("pad_log2", n): culling pad = 2^-n of the coordinates' magnitude (A/B; before prt_set_scene)
     int node_stride = 0;      // prt_set_param("node_stride", 5 | 8): uint4 per 8-wide node slot, 0 = by tree size (upload_scene); before prt_set_scene
     int compact_primary = 1;  // prt_set_param("compact_primary", 0): k_raygen stores full ray records (A/B)
     int gpu_build = 0;  // prt_set_param("gpu_build", 1): the next prt_set_scene builds the 8-wide tree on the device
@@ -726,7 +727,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.max_depth = c->bvh.max_depth;
     bi.max_leaf_size = c->bvh.max_leaf;
     bi.sah_cost = c->bvh.sah_cost;
-    bi.pad_abs = kPadCoeff;
+    bi.pad_abs = c->pad_coeff;
     bi.node_bytes = (uint64_t)c->bvh.nodes4.size() * 4;
     bi.n_nodes4 = (uint32_t)(c->bvh.nodes4.size() / 32);
     bi.max_stack4 = c->bvh.max_stack4;
@@ -741,7 +742,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     d.n_prims = n_prims;
     d.n_nodes = gpu_build ? (uint32_t)(c->bvh.nodes8.size() / 20) : bi.n_nodes;  // "the scene has a BVH" for the producers' classification
     d.n_tris = (uint32_t)n_tris;
-    d.pad = kPadCoeff;
+    d.pad = c->pad_coeff;
     d.extent = extent;
     memcpy(d.sky, s->sky, sizeof(d.sky));
     for (int k = 0; k < 3; ++k) {
@@ -1536,6 +1537,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
     else if (n == "compact_primary" && (value == 0 || value == 1)) c->compact_primary = value;
     else if (n == "node_stride" && (value == 0 || value == 5 || value == 8)) c->node_stride = value;
+    else if (n == "pad_log2" && value >= 8 && value <= 22) c->pad_coeff = std::ldexp(1.0f, -value);
     else if (n == "tail" && value >= 0 && value <= 64) c->tune.tail = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;
     else if (n == "prim_bvh" && (value == 0 || value == 1)) c->abvh_enabled = value;

@@ -86,3 +86,22 @@ def test_grazing_rays_from_far_away_keep_the_reference_spheres_phantom_hits():
     miss_by = np.linalg.norm(np.cross(oo - centres[i], dd), axis=1) - radii[i]
     phantom = (want["prim"] == i) & (miss_by > 1e-6 * dist)
     assert phantom.sum() > 100, int(phantom.sum())
+
+
+def test_grazing_rays_along_triangle_edges_down_to_a_sixth_of_a_degree():
+    """The adversarial case for box culling against Triangle::Intersect's rounding (shape.h:262-303): rays that graze a
+    triangle's plane, travel along one of its edges and cross the plane within a few rounding errors of that edge, on
+    meshes whose leaf boxes are tight there.  Down to a cosine of incidence of 3e-3 (0.17 degrees) the traversal returns
+    what the oracle's brute-force scan returns.  Below that the reference's barycentrics are dominated by rounding (lateral
+    error 3u * dist / cos: a quarter of a unit at cos 1e-5 from 14 units away) and it reports hits on triangles the ray does
+    not come near; no spatial culling can follow it there: tools/graze_probe.py, DESIGN.md section 0."""
+    spec = importlib.util.spec_from_file_location("graze_probe", os.path.join(util.ROOT, "tools", "graze_probe.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    gp.a.n, gp.a.cos_lo, gp.a.cos_hi = 150_000, 3e-3, 0.08
+    for build in (0, 1):
+        gp.a.gpu_build = build
+        assert gp.probe("axis-aligned planar grid", *gp.grid_mesh()) == 0
+        assert gp.probe("tilted planar grid", *gp.tilted_grid()) == 0
+        m = util.prt.scenes.refined("bunny.ply", 12_000)
+        assert gp.probe("bunny 12 k", m.GetVertices(), m.GetNormals(), m.GetIndices()) == 0
