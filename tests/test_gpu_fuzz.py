@@ -105,3 +105,16 @@ def test_grazing_rays_along_triangle_edges_down_to_a_sixth_of_a_degree():
         assert gp.probe("tilted planar grid", *gp.tilted_grid()) == 0
         m = util.prt.scenes.refined("bunny.ply", 12_000)
         assert gp.probe("bunny 12 k", m.GetVertices(), m.GetNormals(), m.GetIndices()) == 0
+
+
+def test_random_call_sequences_on_one_long_lived_renderer():
+    """ProgressiveRender in chunks, SetCamera, film Clear, sampling flags, samples in flight, run-time tunables, re-Init with
+    another scene and film size, on one context or on a group of 2-3 contexts sharing the GPU (prt_group_*): after every
+    render the film equals what the oracle accumulates for the same sequence (the reference's call contract:
+    src/main.cpp:481-509, one more sample per ProgressiveRender, the caller clears the film)."""
+    bad = []
+    for case in range(60):
+        msg, ok = fuzz.run_sequence_case(case, seed=13)
+        if not ok:
+            bad.append(msg)
+    assert bad == []

@@ -181,18 +181,104 @@ def run_ray_case(case, seed, n=4096):
     return f"ray case {case}: {'ok ' if ok else 'MISMATCH ' + str(bad)} [{desc}] params {params}: {nhit} of {n} hit", ok
 
 
+def run_sequence_case(case, seed):
+    """ONE long-lived renderer driven through a random sequence of the interface's calls (ProgressiveRender in chunks of
+    any size, SetCamera, film Clear, sampling flags, samples in flight, run-time tunables, re-Init with another scene, a
+    second film size, a group of 2-3 contexts on the same GPU): after every render the film must equal what the oracle
+    accumulates for the same sequence (samples first_sample .. of the current camera / scene / flags added in order)."""
+    rng = np.random.default_rng([seed, case, 4242])
+    depth = int(rng.integers(1, 7))
+    rseed = int(rng.integers(0, 1 << 30))
+    use_group = rng.random() < 0.25
+    k_ctx = int(rng.integers(2, 4))
+    r = prt.HipWavefrontGroupRenderer([0] * k_ctx, max_depth=depth, seed=rseed) if use_group else \
+        prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=rseed)
+    log = [f"group x{k_ctx}" if use_group else "single"]
+    state = {}
+
+    def new_camera(W, H):
+        pos = rng.normal(size=3)
+        pos = pos / np.linalg.norm(pos) * rng.uniform(3, 12)
+        pos[1] = abs(pos[1]) + 0.3
+        return prt.Camera(position=tuple(float(v) for v in pos), front=tuple(float(v) for v in (-pos + rng.uniform(-1, 1, 3))), width=W, height=H)
+
+    def init():
+        scene, desc, kind, _ = random_scene(rng)
+        W, H = int(rng.choice([17, 40, 96])), int(rng.choice([9, 33, 48]))
+        film = prt.Film(W, H)
+        cam = new_camera(W, H)
+        if not use_group and kind != "none" and rng.random() < 0.4:
+            r.set_param("gpu_build", int(rng.choice([0, 1, 2])))
+        r.Init(film, scene, cam)
+        state.update(scene=scene, osc=orc.OracleScene(scene.desc()), W=W, H=H, film=film, cam=cam, fi=0, sp=None,
+                     acc=np.zeros((H, W, 3), np.float32), wts=np.zeros((H, W), np.float32), rays=0)
+        r.set_sampling(0, 0, 0.0)
+        log.append(f"Init {W}x{H} [{desc}]")
+
+    init()
+    n_ops = int(rng.integers(4, 14))
+    for _ in range(n_ops):
+        op = rng.choice(["render", "render", "render", "camera", "clear", "sampling", "sif", "param", "reinit"])
+        if op == "render":
+            k = int(rng.integers(1, 5))
+            if use_group:
+                r.frame_index = state["fi"]
+            r.ProgressiveRender(k)
+            st = state
+            st["osc"].render(st["cam"].desc(), st["W"], st["H"], spp=k, first_sample=st["fi"], max_depth=depth, seed=rseed,
+                             iterative=True, use_bvh=st["scene"].n_triangles > 6000, n_threads=8, accum=st["acc"],
+                             weights=st["wts"], sampling=st["sp"])
+            st["fi"] += k
+            f = r.download()
+            log.append(f"render {k}")
+            if not (np.array_equal(f.accum, st["acc"]) and np.array_equal(f.weights, st["wts"])):
+                nbad = int((f.accum != st["acc"]).any(axis=-1).sum())
+                return f"sequence case {case}: MISMATCH after {log}: {nbad} bad pixels", False
+        elif op == "camera":
+            state["cam"] = new_camera(state["W"], state["H"])
+            r.SetCamera(state["cam"])
+            log.append("SetCamera")
+        elif op == "clear":
+            if use_group:
+                r.Clear()
+            else:
+                state["film"].Clear()
+                r.frame_index = 0
+            state["fi"] = 0
+            state["acc"][:] = 0
+            state["wts"][:] = 0
+            log.append("Clear")
+        elif op == "sampling":
+            state["sp"] = r.set_sampling(jitter=int(rng.integers(0, 2)), rr_depth=int(rng.choice([0, 1, 3])), clamp=float(rng.choice([0.0, 1.5])))
+            if state["sp"].jitter == 0 and state["sp"].rr_depth == 0 and state["sp"].clamp == 0.0:
+                state["sp"] = None
+            log.append("sampling")
+        elif op == "sif":
+            r.set_samples_in_flight(int(rng.integers(1, 6)))
+            log.append("sif")
+        elif op == "param":
+            name, val = [("fuse", int(rng.integers(0, 2))), ("exact_grids", int(rng.integers(0, 3))), ("refill_min", int(rng.choice([1, 16, 64]))),
+                         ("tri_min", int(rng.choice([1, 24, 64]))), ("compact_primary", int(rng.integers(0, 2))), ("steal", int(rng.choice([0, 8])))][int(rng.integers(0, 6))]
+            r.set_param(name, val)
+            log.append(f"{name}={val}")
+        else:
+            init()
+    return f"sequence case {case}: ok  {log}", True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sequences", action="store_true", help="random call sequences on one long-lived renderer (or a group of contexts)")
     ap.add_argument("--rays", action="store_true", help="closest-hit cases with awkward rays against the brute-force scan")
     a = ap.parse_args()
     t0 = time.time()
     bad = 0
     for case in range(a.first, a.first + a.cases):
-        msg, ok = run_ray_case(case, a.seed) if a.rays else run_case(case, a.seed)
+        msg, ok = run_ray_case(case, a.seed) if a.rays else run_sequence_case(case, a.seed) if a.sequences else run_case(case, a.seed)
         if not ok:
             bad += 1
         if a.verbose or not ok or "refused" in msg:
