@@ -151,3 +151,16 @@ def test_config_c5_ten_million_triangles(name, c5_images):
         close = np.isclose(a, b, rtol=1e-3, atol=1e-3).all(axis=-1)
         assert close.mean() > 0.98, close.mean()
         assert abs(a.mean() - b.mean()) < 0.01 * a.mean()
+
+
+def test_config_c3_closest_hits_against_the_brute_force_scan_over_all_870k_triangles():
+    """configs[2]'s scene with NO tree on the checker's side: camera rays, diffuse bounce rays leaving the surface, awkward
+    rays (zero direction components, axis-parallel, lattice origins) and far-away rays against the oracle's linear scan
+    over every triangle, i.e. literally PrimitiveList::Intersect (primitive.cpp:21-59) at full size.  The same tool run
+    on C5 and C5I (10.44 M triangles, 66 s of brute force per 3,700 rays) is recorded in profiles/r2_bruteforce_fullsize.txt."""
+    import subprocess
+    import sys
+    import os
+    out = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "bruteforce_fullsize.py"), "--config", "C3", "--n", "4096"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "bit-exact" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
