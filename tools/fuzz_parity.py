@@ -266,6 +266,59 @@ def run_sequence_case(case, seed):
     return f"sequence case {case}: ok  {log}", True
 
 
+def run_graze_case(case, seed, n=100_000):
+    """Spheres only, more than 16 of them (so the walk over their world boxes runs), rays aimed to graze them within a few
+    rounding margins of the reference's discriminant (2e-7 * dist^2 / R), from 0.5 ... 2000 units away, random radii down
+    to 0.01 and scales; against the oracle's linear scan."""
+    rng = np.random.default_rng([seed, case, 991])
+    sc = prt.Scene(preset=None)
+    mat = sc.AddLambertian((0.7, 0.7, 0.7))
+    k = int(rng.integers(17, 120))
+    centres, radii = [], []
+    spread = float(rng.choice([2.0, 8.0, 40.0]))
+    for _ in range(k):
+        c = rng.uniform(-spread, spread, 3)
+        s = float(np.exp(rng.uniform(np.log(0.1), np.log(3.0))))
+        r = float(np.exp(rng.uniform(np.log(0.01), np.log(1.0))))
+        sc.AddCircle(r, mat, scale=(s, s, s), translation=tuple(float(v) for v in c))
+        centres.append(c)
+        radii.append(r * s)
+    if rng.random() < 0.3:  # the classic ground: one huge sphere
+        sc.AddCircle(1000.0, mat, translation=(0.0, -1000.0 - spread, 0.0))
+    centres, radii = np.array(centres), np.array(radii)
+    i = rng.integers(0, k, n)
+    lo, hi = [(0.5, 30.0), (5.0, 300.0), (30.0, 2000.0)][int(rng.integers(0, 3))]
+    dist = np.exp(rng.uniform(np.log(lo), np.log(hi), n)) + radii[i] * 1.01
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3))
+    v -= (v * u).sum(1, keepdims=True) * u
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    m = rng.uniform(-3e-7, 6e-7, n) * dist * dist / radii[i]
+    ang = np.arcsin(np.clip((radii[i] + m) / dist, 0.0, 1.0))
+    o = (centres[i] + u * dist[:, None]).astype(np.float32)
+    d = (-u * np.cos(ang)[:, None] + v * np.sin(ang)[:, None]).astype(np.float32)
+    inv = 1.0 / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d * inv[:, None]).astype(np.float32)  # (x * (1 / sqrt(dot)): glm's normalize, vectorised)
+    r = prt.HipWavefrontRenderer(device=0, max_depth=2, seed=0)
+    r.Init(prt.Film(16, 16), sc, prt.Camera(position=(5.0, 5.0, 8.0), width=16, height=16))
+    got = r.closest_hit(o, d)
+    want = orc.OracleScene(sc.desc()).closest_hit(o, d, use_bvh=False, n_threads=16)
+    bad = []
+    for f in ("prim", "front_face", "material_id", "d2", "position", "normal"):
+        same = got[f] == want[f]
+        if got[f].dtype.kind == "f":
+            same = same | (np.isnan(got[f]) & np.isnan(want[f]))
+        if not np.all(same):
+            bad.append(f)
+    oo, dd = o.astype(np.float64), d.astype(np.float64)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    miss_by = np.linalg.norm(np.cross(oo - centres[i], dd), axis=1) - radii[i]
+    phantom = int(((want["prim"] == i) & (miss_by > 1e-6 * dist)).sum())
+    ok = bad == []
+    return f"graze case {case}: {'ok ' if ok else 'MISMATCH ' + str(bad)} {k} spheres, spread {spread}, dist {lo}..{hi}: {phantom} phantom hits in {n} rays", ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -273,12 +326,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--sequences", action="store_true", help="random call sequences on one long-lived renderer (or a group of contexts)")
+    ap.add_argument("--graze", action="store_true", help="rays grazing spheres within the reference's rounding margins (walk over the primitives' boxes)")
     ap.add_argument("--rays", action="store_true", help="closest-hit cases with awkward rays against the brute-force scan")
     a = ap.parse_args()
     t0 = time.time()
     bad = 0
     for case in range(a.first, a.first + a.cases):
-        msg, ok = run_ray_case(case, a.seed) if a.rays else run_sequence_case(case, a.seed) if a.sequences else run_case(case, a.seed)
+        msg, ok = (run_ray_case(case, a.seed) if a.rays else run_sequence_case(case, a.seed) if a.sequences else
+                   run_graze_case(case, a.seed) if a.graze else run_case(case, a.seed))
         if not ok:
             bad += 1
         if a.verbose or not ok or "refused" in msg:
