@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Closest hits on a FULL-SIZE config scene against the oracle's BRUTE-FORCE scan over every triangle (the reference's
 PrimitiveList::Intersect, primitive.cpp:21-59; no tree on the checker's side): camera rays, diffuse bounce rays leaving the
-surface, and the awkward families of tools/fuzz_parity.py --rays.   python tools/bruteforce_fullsize.py --config C3 --n 8192"""
+surface, and the awkward families of tests/fuzz_parity.py --rays.   python tests/bruteforce_fullsize.py --config C3 --n 8192"""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import util  # noqa: E402
 from util import prt  # noqa: E402
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomized parity: random scenes (analytic primitives of every material, refined meshes, placed copies), random cameras,
 builders, kernel tunables and sampling flags; every frame bit for bit against the oracle (throughput form) + ray counts.
-  python tools/fuzz_parity.py --cases 200 --seed 1      (GPU box; ~0.3 s per case)
-Uses the oracle, i.e. test infrastructure: this is a checker, not a product path."""
+  python tests/fuzz_parity.py --cases 200 --seed 1      (GPU box; ~0.3 s per case)
+Test infrastructure (it calls the oracle): a checker, not a product path; tests/test_gpu_fuzz.py runs a seeded subset."""
 import argparse
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import parallelraytracing_amd as prt  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 

@@ -2,11 +2,11 @@
 """Worst case for box culling against the reference's Triangle::Intersect rounding: rays that graze a triangle's plane,
 travel (nearly) along one of its edges and cross the plane a few rounding errors outside that edge, on meshes whose
 leaf boxes are tight there (an axis-aligned planar grid) and on a general mesh.  GPU closest hit vs the oracle's
-brute-force scan.   python tools/graze_probe.py [--n 400000]"""
+brute-force scan.   python tests/graze_probe.py [--n 400000]"""
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import util  # noqa: E402
 from util import prt  # noqa: E402
 

@@ -2,7 +2,7 @@
 """The reference's own preset scenes (analytic primitives only) at main()'s frame size, 1920x1080, 20 segments
 (src/main.cpp:96-97, src/backend/cpu/renderer.h:34): GPU rate, and the oracle = CPU restatement of the reference CPU
 backend (linear scan over all primitives, recursive TraceRay) on the host cores for comparison.
-  python tools/presets_rate.py [--cpu-rows 16]"""
+  python tests/presets_rate.py [--cpu-rows 16]"""
 import argparse
 import os
 import sys

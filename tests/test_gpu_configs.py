@@ -161,6 +161,6 @@ def test_config_c3_closest_hits_against_the_brute_force_scan_over_all_870k_trian
     import subprocess
     import sys
     import os
-    out = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "bruteforce_fullsize.py"), "--config", "C3", "--n", "4096"],
+    out = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "bruteforce_fullsize.py"), "--config", "C3", "--n", "4096"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "bit-exact" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1,4 +1,4 @@
-"""Randomized parity (-m gpu): tools/fuzz_parity.py's generator, a fixed seed, 200 cases.
+"""Randomized parity (-m gpu): tests/fuzz_parity.py's generator, a fixed seed, 200 cases.
 
 Each case draws a scene (analytic primitives of every material, a refined mesh, placed copies of a second mesh, in any
 combination), a camera, frame size, depth, sample count and batching, one of the three tree builders, the node layout, kernel
@@ -15,7 +15,7 @@ import util  # noqa: F401  (puts the repo root on sys.path)
 
 pytestmark = pytest.mark.gpu
 
-_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(util.ROOT, "tools", "fuzz_parity.py"))
+_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(util.ROOT, "tests", "fuzz_parity.py"))
 fuzz = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(fuzz)
 
@@ -94,8 +94,8 @@ def test_grazing_rays_along_triangle_edges_down_to_a_sixth_of_a_degree():
     meshes whose leaf boxes are tight there.  Down to a cosine of incidence of 3e-3 (0.17 degrees) the traversal returns
     what the oracle's brute-force scan returns.  Below that the reference's barycentrics are dominated by rounding (lateral
     error 3u * dist / cos: a quarter of a unit at cos 1e-5 from 14 units away) and it reports hits on triangles the ray does
-    not come near; no spatial culling can follow it there: tools/graze_probe.py, DESIGN.md section 0."""
-    spec = importlib.util.spec_from_file_location("graze_probe", os.path.join(util.ROOT, "tools", "graze_probe.py"))
+    not come near; no spatial culling can follow it there: tests/graze_probe.py, DESIGN.md section 0."""
+    spec = importlib.util.spec_from_file_location("graze_probe", os.path.join(util.ROOT, "tests", "graze_probe.py"))
     gp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gp)
     gp.a.n, gp.a.cos_lo, gp.a.cos_hi = 150_000, 3e-3, 0.08
