@@ -319,6 +319,59 @@ def run_graze_case(case, seed, n=100_000):
     return f"graze case {case}: {'ok ' if ok else 'MISMATCH ' + str(bad)} {k} spheres, spread {spread}, dist {lo}..{hi}: {phantom} phantom hits in {n} rays", ok
 
 
+def run_graze_quads_case(case, seed, n=100_000, cos_lo=1e-5, cos_hi=0.08):
+    """More than 16 quads (so the walk over the primitives' world boxes runs), rays that graze a quad's plane, travel along
+    one of its edges and cross the plane within a few rounding errors (3u * dist / cos) of it; against the linear scan.
+    Returns the message, ok, and the cosines of incidence of the rays that differ."""
+    rng = np.random.default_rng([seed, case, 555])
+    sc = prt.Scene(preset=None)
+    mat = sc.AddLambertian((0.7, 0.7, 0.7))
+    k = int(rng.integers(17, 60))
+    quads = []
+    for _ in range(k):
+        c = rng.uniform(-6, 6, 3)
+        w, h = float(rng.uniform(0.5, 4.0)), float(rng.uniform(0.5, 4.0))
+        ex = float(rng.choice([0.0, 50.0, 90.0, 180.0, float(rng.uniform(0, 360))]))
+        sc.AddQuad(w, h, mat, euler_deg=(ex, 0.0, 0.0), translation=tuple(float(v) for v in c))
+        a = np.radians(ex)
+        R = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        quads.append((c, w, h, R))
+    i = rng.integers(0, k, n)
+    C = np.array([quads[j][0] for j in i])
+    Wd = np.array([quads[j][1] for j in i])
+    Hd = np.array([quads[j][2] for j in i])
+    Rm = np.array([quads[j][3] for j in i])
+    ax = Rm[:, :, 0]          # local x in world
+    nz = Rm[:, :, 2]          # local z in world
+    nrm = Rm[:, :, 1]         # local y (the normal)
+    along_x = rng.random(n) < 0.5
+    eu = np.where(along_x[:, None], ax, nz)                     # edge direction
+    outw = np.where(along_x[:, None], nz, ax) * rng.choice([-1.0, 1.0], (n, 1))
+    half_out = np.where(along_x, Hd, Wd) * 0.5
+    half_along = np.where(along_x, Wd, Hd) * 0.5
+    dist = np.exp(rng.uniform(np.log(0.5), np.log(40.0), (n, 1)))
+    cosi = np.exp(rng.uniform(np.log(cos_lo), np.log(cos_hi), (n, 1)))
+    psi = rng.uniform(-0.08, 0.08, (n, 1))
+    err = 3 * 6e-8 * dist / cosi
+    off = rng.uniform(-1.0, 3.0, (n, 1)) * err
+    cross_pt = C + eu * (rng.uniform(-0.8, 0.8, (n, 1)) * half_along[:, None]) + outw * (half_out[:, None] + off)
+    g = eu * np.cos(psi) + outw * np.sin(psi)
+    d = g * np.sqrt(1 - cosi ** 2) - nrm * cosi * rng.choice([-1.0, 1.0], (n, 1))
+    o = (cross_pt - d * dist).astype(np.float32)
+    d = d.astype(np.float32)
+    inv = (1.0 / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])).astype(np.float32)
+    d = (d * inv[:, None]).astype(np.float32)
+    r = prt.HipWavefrontRenderer(device=0, max_depth=2, seed=0)
+    r.Init(prt.Film(16, 16), sc, prt.Camera(position=(5.0, 5.0, 8.0), width=16, height=16))
+    got = r.closest_hit(o, d)
+    want = orc.OracleScene(sc.desc()).closest_hit(o, d, use_bvh=False, n_threads=16)
+    diff = (got["prim"] != want["prim"]) | ~((got["d2"] == want["d2"]) | (np.isnan(got["d2"]) & np.isnan(want["d2"])))
+    bad = np.nonzero(diff)[0]
+    ok = len(bad) == 0
+    extra = "" if ok else f"; cosines of the differing rays: min {cosi[bad, 0].min():.2e} max {cosi[bad, 0].max():.2e}"
+    return f"quad graze case {case}: {'ok ' if ok else 'MISMATCH'} {k} quads, {len(bad)} of {n} rays differ{extra}", ok, cosi[bad, 0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -327,13 +380,16 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--sequences", action="store_true", help="random call sequences on one long-lived renderer (or a group of contexts)")
     ap.add_argument("--graze", action="store_true", help="rays grazing spheres within the reference's rounding margins (walk over the primitives' boxes)")
+    ap.add_argument("--graze-quads", action="store_true", help="rays grazing quads along their edges (walk over the primitives' boxes)")
+    ap.add_argument("--cos-lo", type=float, default=1e-5, help="--graze-quads: smallest cosine of incidence")
     ap.add_argument("--rays", action="store_true", help="closest-hit cases with awkward rays against the brute-force scan")
     a = ap.parse_args()
     t0 = time.time()
     bad = 0
     for case in range(a.first, a.first + a.cases):
         msg, ok = (run_ray_case(case, a.seed) if a.rays else run_sequence_case(case, a.seed) if a.sequences else
-                   run_graze_case(case, a.seed) if a.graze else run_case(case, a.seed))
+                   run_graze_case(case, a.seed) if a.graze else
+                   run_graze_quads_case(case, a.seed, cos_lo=a.cos_lo)[:2] if a.graze_quads else run_case(case, a.seed))
         if not ok:
             bad += 1
         if a.verbose or not ok or "refused" in msg:
