@@ -348,6 +348,10 @@ def main():
                      "valu_per_node_step": isa["node_step"], "valu_per_triangle_round": isa["triangle_round"],
                      "isa_source": isa["source"],
                      "peak_def": "1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+                     # the same achieved rate against the roof the round-1 review wrote down (a wave64 instruction every 4
+                     # cycles per SIMD: 614.4 G/s); the line's own frac uses the stricter 2-cycle figure, which is what the
+                     # fp32 vector peak of the part implies and what v_fma_f32 was measured to sustain (profiles/r2_issue_rate.txt)
+                     "frac_at_4_cycles_per_instr": round(valu_frac * 2.0, 4),
                      # the hardware's own count of the same launches, and where the wave cycles went (committed PMC pass)
                      "valu_insts_measured": sq_p.get("valu_insts_per_launch") if sq_p else None,
                      "frac_measured": round(sq_p["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if sq_p else None,
