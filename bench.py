@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Mrays/s of the wavefront path tracer on BASELINE.json's metric config.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its N ranks as child processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): C3 of SURVEY.md §8(d) — the bundled dragon.ply refined by deterministic
@@ -189,8 +189,66 @@ def presets_block(prt, torch, orc, device, cores, cpu_seconds):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as CHILD processes of this
+    one and forward rank 0's JSON line.  Nothing in this parent touches the GPU (no torch import, no HIP call: the build is
+    a hipcc / g++ child process), so no process that has initialised the GPU is ever replaced or forked.  Any rank
+    failing fails the run: the others are terminated and the exit code is non-zero."""
+    import socket
+    import subprocess
+
+    import __graft_entry__ as g
+    g.build(quiet=True, load=False)  # once, here: the ranks then find everything up to date
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for rk in range(args.gpus):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PRT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True))
+    out0 = ""
+    rc = 0
+    try:
+        # rank 0 prints the line after the last collective; poll all ranks so that one dying early ends the run instead
+        # of leaving the others in a rendezvous
+        live = set(range(args.gpus))
+        while live:
+            for rk in sorted(live):
+                p = procs[rk]
+                try:
+                    if rk == 0:
+                        o, _ = p.communicate(timeout=0.5)
+                        out0 += o or ""
+                    else:
+                        p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                live.discard(rk)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    print(f"bench.py: rank {rk} exited with code {p.returncode}", file=sys.stderr)
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)  # does not return
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprt.so")
+# PRT_LIB_PATH: tuning hook (tools/ab_libs.py times alternative BUILDS of the same sources, e.g. other compiler flags)
+LIB_PATH = os.environ.get("PRT_LIB_PATH") or os.path.join(_HERE, "csrc", "libprt.so")
 
 PRT_MAX_DEPTH = 64
 

@@ -75,3 +75,21 @@ def test_two_rank_tile_gather_on_gloo():
 def test_three_rank_tile_gather_on_gloo():
     outs = _run(3)  # tiles do not divide evenly: exercises the padded payload stride
     assert "GLOO_OK" in outs[0]
+
+
+def test_bench_self_launch_forwards_a_rank_failure_as_a_non_zero_exit():
+    """`python bench.py --gpus 2` with no launcher starts its ranks as child processes (the parent touches no GPU).  Here,
+    without a GPU, every rank stops with "needs an MI355X": the parent must report it and exit non-zero, not hang in a
+    rendezvous and not print a result line.  (On the GPU box tests/test_gpu_dist.py runs the same entry to a real frame.)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the GPU box runs the successful case instead (tests/test_gpu_dist.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "exited with code" in p.stderr and "needs an MI355X" in p.stderr
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())

@@ -38,13 +38,18 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo_matches_one_rank(tmp_path):
 
     import numpy as np
     outs = {}
-    for n in (1, 2):
+    # "self": plain `python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts its two ranks itself
+    for n in (1, 2, "self"):
         dump = str(tmp_path / f"f{n}")
-        args = ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--config", "C2", "--spp-per-step", "2", "--no-cpu-baseline",
-                "--no-secondary", "--dump", dump]
+        args = ["--gpus", "1" if n == 1 else "2", "--steps", "1", "--warmup", "0", "--config", "C2", "--spp-per-step", "2",
+                "--no-cpu-baseline", "--no-secondary", "--dump", dump]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PRT_BENCH_SAME_DEVICE="1")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
         if n == 1:
             cmd = [sys.executable, os.path.join(util.ROOT, "bench.py")] + args
+        elif n == "self":
+            cmd = [sys.executable, os.path.join(util.ROOT, "bench.py")] + args + ["--backend", "gloo"]
         else:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port()), os.path.join(util.ROOT, "bench.py")] + args + ["--backend", "gloo"]
@@ -52,11 +57,12 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo_matches_one_rank(tmp_path):
         assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
         line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1]
         outs[n] = (json.loads(line), open(dump + ".pfm", "rb").read())
-    assert outs[1][0]["ranks_seen"] == 1 and outs[2][0]["ranks_seen"] == 2 and outs[2][0]["n_gpus"] == 2
-    assert outs[1][0]["config"]["rays_timed"] == outs[2][0]["config"]["rays_timed"]
+    assert outs[1][0]["ranks_seen"] == 1
     a = np.frombuffer(outs[1][1][-1280 * 720 * 12:], "<f4")
-    b = np.frombuffer(outs[2][1][-1280 * 720 * 12:], "<f4")
-    assert np.array_equal(a, b)
+    for n in (2, "self"):
+        assert outs[n][0]["ranks_seen"] == 2 and outs[n][0]["n_gpus"] == 2, n
+        assert outs[1][0]["config"]["rays_timed"] == outs[n][0]["config"]["rays_timed"], n
+        assert np.array_equal(a, np.frombuffer(outs[n][1][-1280 * 720 * 12:], "<f4")), n
 
 
 # ---- the C/C++ multi-GPU host path (include/prt.h prt_group_*) ----------------------------------------------------------

@@ -36,7 +36,7 @@ INSTANCES = {
 
 
 def compile_asm(tmp):
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
            "--offload-arch=gfx950", "-c", os.path.join(CSRC, "prt_kernels.hip"), "-o", os.path.join(tmp, "k.o"),
            "-save-temps=obj"]
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
