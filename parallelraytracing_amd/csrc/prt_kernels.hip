@@ -1529,7 +1529,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 // A ray that would need more than STACK_L stacked groups goes to the overflow list (re-traversed by the 4-wide
 // spill-capable instance); the host sizes STACK_L from the tree's depth, so that never happens in practice.
 // ---------------------------------------------------------------------------------------------------------
-#define T8_QCAP 256u  // work items of one wave between two triangle phases
+#define T8_QCAP 256u    // (ray, triangle) pairs one pass of a triangle phase tests (4 B each)
+#define T8_QGROUPS 128u // triangle groups a wave can queue between two phases (8 B each, the same memory)
 
 // INST = true (scenes with placed mesh copies, PrtInstance): nodes8 starts with a TOP-LEVEL tree whose "triangles" are
 // instances.  A lane that finds instance hits there saves its top-level group, pushes a sentinel and restarts in the
@@ -1553,6 +1554,27 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 #else
 #define T8_SEL(M, A, B) ((M) ? (A) : (B))
 #endif
+// how a child's hit bits enter the mask.  0: compare + select (the compiler emits v_cmp -> vcc, v_cndmask_b32_e32);
+// 1: the same compare into an SGPR pair and the VOP3 select on it (A/B: the vcc form of v_cndmask measured 4x the issue
+// cost of the SGPR-pair form in isolation, profiles/r2_issue_rate.txt); 2: sign of tf - tn, no compare (tf - tn has the
+// exact sign of the comparison; a NaN from inf - inf counts as a hit, which is the conservative side)
+#ifndef PRT_T8_HITSEL
+#define PRT_T8_HITSEL 0
+#endif
+#if PRT_T8_HITSEL == 1
+#define T8_HIT(TN, TF, CB)                                                                       \
+    {                                                                                            \
+        unsigned long long hm_;                                                                  \
+        uint32_t hv_;                                                                            \
+        asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(hm_) : "v"(TN), "v"(TF));                       \
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hv_) : "v"(CB), "s"(hm_));                  \
+        hitmask |= hv_;                                                                          \
+    }
+#elif PRT_T8_HITSEL == 2
+#define T8_HIT(TN, TF, CB) hitmask |= (CB) & ~(uint32_t)((int32_t)__float_as_uint((TF) - (TN)) >> 31);
+#else
+#define T8_HIT(TN, TF, CB) hitmask |= ((TN) <= (TF)) ? (CB) : 0u;
+#endif
 #define T8_CHILD(J, NX, FX, NY, FY, NZ, FZ)                                                                          \
     {                                                                                                                \
         const float tnx = __builtin_fmaf((float)(((NX) >> (8 * J)) & 0xFFu), Ax, Bnx);                               \
@@ -1564,7 +1586,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));                     \
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlimit));                   \
         const uint32_t cb = ((bits4 >> (8 * J)) & 0xFFu) << ((idx4 >> (8 * J)) & 0xFFu);                             \
-        hitmask |= (tn <= tf) ? cb : 0u;                                                                             \
+        T8_HIT(tn, tf, cb)                                                                                           \
     }
 #define T8_HALF(META4, NX, FX, NY, FY, NZ, FZ)                                                                       \
     {                                                                                                                \
@@ -1609,8 +1631,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     __shared__ uint2 s_stack[(STACK_L + 1) * 256];  // [entry][thread]; one row of slack above the top
     __shared__ unsigned long long s_key[256];       // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
     __shared__ uint32_t s_slot[256];                // per lane: leaf-order slot of that best
-    __shared__ uint32_t s_queue[4 * T8_QCAP];       // per wave: (owner lane << 26) | triangle slot
-    __shared__ uint32_t s_qn[8];                    // per wave: [w] items appended so far, [4 + w] first position that did not fit
+    // per wave, between two triangle phases: up to T8_QGROUPS 8-byte GROUP items {first triangle slot, owner lane << 24 |
+    // 24-bit triangle mask} appended by the node loop; the triangle phase takes them into registers and expands them IN
+    // PLACE into up to T8_QCAP 4-byte PAIR items (owner lane << 26) | triangle slot, one per lane per round
+    __shared__ uint32_t s_queue[4 * T8_QCAP];
+    __shared__ uint32_t s_qn[8];                    // per wave: [w] group items appended since the last triangle phase
     __shared__ uint32_t s_iters[8];                 // [0..3] node-loop, [4..7] triangle-loop iterations per wave (STATS)
     __shared__ float s_wray[INST ? 6 * 256 : 1];    // INST: the lane's WORLD ray (origin, raw direction), [component][thread]
     // LEAN (5 waves per SIMD: <= 96 VGPRs): what only the triangle phase needs lives in LDS instead of registers: the
@@ -1651,7 +1676,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     const uint32_t wbase = tid & ~63u;
     if (tid < 8) {
         s_iters[tid] = 0;
-        s_qn[tid] = tid < 4 ? 0u : T8_QCAP;
+        s_qn[tid] = 0u;
     }
     __syncthreads();
     uint32_t* const queue = &s_queue[wv * T8_QCAP];
@@ -1660,7 +1685,6 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     float ix = 1.f, iy = 1.f, iz = 1.f, anx = 0.f, any = 0.f, anz = 0.f, afx = 0.f, afy = 0.f, afz = 0.f, pad = 0.f, tlimit = 0.f;
     uint32_t octinv4 = 0x07070707u;  // (7 - direction octant) in every byte
     uint32_t gx = 0u, gy = 0u;    // current node group
-    uint32_t tBb = 0u, tBm = 0u;  // a triangle group that did not fit the queue (the lane waits for the next phase)
     bool pending = false;         // this lane has items in the wave's queue
     // INST only: level (0 = top-level tree, world ray; 1 = inside an instance, local ray), the instance, the pending
     // instance hits of the current top-level node, the culling-bound conversion (world distance -> local parameter)
@@ -1676,7 +1700,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     uint32_t n_nodes = 0, n_tris = 0, max_sp = 0;
     uint32_t cur = 0, cur_end = 0;  // wave-uniform: this wave's current chunk [cur, cur_end)
     bool exhausted = false;         // wave-uniform
-    uint32_t q_lanes = 0;           // wave-uniform: lane-steps that queued triangles since the last phase (<= items)
+    // a triangle phase starts once this many triangle groups are queued; at most 63 more arrive with the step that reaches it
+    const uint32_t tri_min = tune.tri_min < T8_QGROUPS - 64u ? tune.tri_min : T8_QGROUPS - 64u;
     // STATS: shader cycles (s_memtime) this wave spent in the three sections of an outer iteration
     unsigned long long cyc_refill = 0, cyc_node = 0, cyc_tri = 0, t_mark = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     // launch timeline (PRT_TIMELINE_WORDS): s_memrealtime is the constant 100 MHz clock all XCDs share (s_memtime, used
@@ -1698,7 +1723,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 helped |= 1ull << ((uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(hm)) & 63u);
         }
         // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
-        if (k != 0xFFFFFFFFu && !pending && tBm == 0u && !(INST && (in_blas || ipm != 0u))) {
+        if (k != 0xFFFFFFFFu && !pending && !(INST && (in_blas || ipm != 0u))) {
             if (overflow) {
                 if (INST) {
                     atomicOr(work + 256, 2u);  // no fallback for two-level scenes: prt_synchronize reports it
@@ -1941,7 +1966,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         }
         // ---- phase 1: node steps.  Triangles found go straight to the wave's queue and the lane keeps walking;
         // leave when at most exit_max lanes can still walk or enough work for a triangle phase has piled up ----
-        bool walk = (k != 0xFFFFFFFFu) && tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u)) && !(INST && stall);
+        bool walk = (k != 0xFFFFFFFFu) && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u)) && !(INST && stall);
+        // Triangle groups queued by this run of the node loop.  The queue is empty on entry (a triangle phase tests all of
+        // it), every lane still in the loop adds the same ballot counts, and a lane that has left the loop does not come
+        // back before the next phase: the lanes in the loop agree on it, so a slot is base + rank in the ballot, without
+        // an atomic and without a per-triangle loop in the node step.
+        uint32_t q_groups = 0u;
         while (walk) {
             // current group: G while it has pending internal hits, else the top of the stack (read unconditionally)
             const int spr = sp > 0 ? sp - 1 : 0;
@@ -1953,7 +1983,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 if (enter || leave) {  // level switches are done by the whole wave together, next to the refill
                     stall = true;
                     walk = false;
-                    if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
+                    if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_groups >= tri_min) break;
                     continue;
                 }
             }
@@ -1978,11 +2008,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             T8_BOXTEST()
             gx = w1.x;
             gy = (hitmask & 0xFF000000u) | (eim >> 24);
-            const uint32_t tm = hitmask & 0x00FFFFFFu;
+            uint32_t tm = hitmask & 0x00FFFFFFu;
             if (sp > stack_cap) {  // give the ray up; it is re-traversed through the overflow list
                 overflow = true;
                 gy = 0u;
                 sp = 0;
+                tm = 0u;
                 if (INST) {
                     ipm = 0u;
                     in_blas = false;
@@ -1990,105 +2021,109 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             } else if (INST && !in_blas) {  // top-level node: its "triangles" are instances, entered one by one
                 ipb = w1.y;
                 ipm = tm;
-            } else if (tm != 0u) {
-                const uint32_t cnt = (uint32_t)__popc(tm);
-                const uint32_t pos = atomicAdd(&s_qn[wv], cnt);
-                if (pos + cnt <= T8_QCAP) {
-                    uint32_t qp = pos;
-                    const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;  // a helper's tests belong to its root
-                    for (uint32_t m = tm; m; m &= m - 1u) queue[qp++] = (own << 26) | (w1.y + (uint32_t)__builtin_ctz(m));
-                    pending = true;
-                } else {  // queue full (everything appended later fails as well): wait for the next phase
-                    atomicMin(&s_qn[4 + wv], pos);
-                    tBb = w1.y;
-                    tBm = tm;
-                }
+                tm = 0u;
             }
-            q_lanes += (uint32_t)__popcll(__ballot(tm != 0u && !(INST && !in_blas)));
-            walk = tBm == 0u && ((gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u));
-            if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_lanes >= tune.tri_min) break;
+            const unsigned long long qm = __ballot(tm != 0u);
+            if (tm != 0u) {
+                const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;  // a helper's tests belong to its root
+                const uint32_t pos = q_groups + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                ((uint2*)queue)[pos] = make_uint2(w1.y, (own << 24) | tm);
+                s_qn[wv] = q_groups + (uint32_t)__popcll(qm);  // (the same value from every queueing lane)
+                pending = true;
+            }
+            q_groups += (uint32_t)__popcll(qm);
+            walk = (gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u);
+            if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_groups >= tri_min) break;
         }
         if (STATS) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             cyc_node += t - t_mark;
             t_mark = t;
         }
-        // ---- phase 2: the queued (ray, triangle) pairs, one pair per lane per round ----
+        // ---- phase 2: the queued triangle groups become (ray, triangle) pairs, one pair per lane per round ----
         {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            const uint32_t qn = ((volatile uint32_t*)s_qn)[wv], qv = ((volatile uint32_t*)s_qn)[4 + wv];
-            const uint32_t T0 = qn < qv ? qn : qv;  // valid prefix of the queue
-            const uint32_t cntB = (uint32_t)__popc(tBm);
-            if (T0 != 0u || __ballot(cntB != 0u) != 0ull) {  // wave-uniform
-                // groups that did not fit are appended now, in lane order, as far as they fit
-                const uint32_t incl = wave_scan_add(cntB);
-                const bool fits = T0 + incl <= T8_QCAP;  // true for a prefix of the lanes
-                const uint32_t n_fit = (uint32_t)__popcll(__ballot(fits));
-                const uint32_t T = n_fit ? T0 + (uint32_t)__shfl((int)incl, (int)(n_fit - 1u), 64) : T0;
-                if (fits && cntB) {
-                    uint32_t qp = T0 + incl - cntB;
-                    const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;
-                    for (uint32_t m = tBm; m; m &= m - 1u) queue[qp++] = (own << 26) | (tBb + (uint32_t)__builtin_ctz(m));
-                    tBm = 0u;
-                }
+            const uint32_t G = ((volatile uint32_t*)s_qn)[wv];  // group items in the queue (wave-uniform)
+            if (G != 0u) {
                 // a miss is encoded with prim 0 so that a candidate with d2 == FLT_MAX can never win (primitive.cpp:44)
                 const unsigned long long key_best =
                     LEAN ? 0ull : ((unsigned long long)__float_as_uint(best.d2) << 32) | (best.id == HIT_MISS ? 0u : best.prim);
                 if (!LEAN) s_key[tid] = key_best;
-                if (lane == 0) {
-                    s_qn[wv] = 0u;
-                    s_qn[4 + wv] = T8_QCAP;
-                }
+                if (lane == 0) s_qn[wv] = 0u;
+                // Sets of 64 group items, one per lane, taken into registers; after that the queue memory holds pair items.
+                // While a second set waits (G > 64: rare, the node loop stops at tri_min groups) the pairs of the first one
+                // stay in the lower half of the queue's memory, below the second set's items.
+                for (uint32_t g0 = 0u; g0 < G; g0 += 64u) {  // wave-uniform, at most two trips
+                const uint32_t cap = (G - g0 > 64u) ? T8_QCAP / 2u : T8_QCAP;
+                const unsigned long long ga = g0 + lane < G ? ((volatile unsigned long long*)queue)[g0 + lane] : 0ull;
+                const uint32_t base_a = (uint32_t)ga, own_a = (uint32_t)(ga >> 56);
+                uint32_t ma = (uint32_t)(ga >> 32) & 0x00FFFFFFu;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                for (uint32_t base = 0; base < T; base += 64u) {  // wave-uniform trip count
-                    const uint32_t kq = base + lane;
-                    const bool act = kq < T;
-                    const uint32_t item = ((volatile uint32_t*)queue)[act ? kq : 0u];
-                    const uint32_t owner = act ? (item >> 26) : lane;
-                    const uint32_t slot = item & 0x03FFFFFFu;
-                    f3 qo, qd;
-                    if (LEAN) {
-                        const uint32_t oc = wbase + owner;
-                        qo = mk3(s_lray[0 * 256 + oc], s_lray[1 * 256 + oc], s_lray[2 * 256 + oc]);
-                        qd = mk3(s_lray[3 * 256 + oc], s_lray[4 * 256 + oc], s_lray[5 * 256 + oc]);
-                    } else {
-                        qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
-                        qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
+                // passes of at most `cap` pairs (one pass unless the set holds more: 2-3 triangles per group on average);
+                // groups are expanded in queue order, whole groups only (a group has at most 24 triangles: progress)
+                while (__ballot(ma != 0u) != 0ull) {  // wave-uniform
+                    const uint32_t ca = (uint32_t)__popc(ma);
+                    const uint32_t ia = wave_scan_add(ca);
+                    const bool fit_a = ia <= cap;  // true for a prefix of the lanes
+                    const uint32_t nfa = (uint32_t)__popcll(__ballot(fit_a));
+                    const uint32_t T = (uint32_t)__shfl((int)ia, (int)(nfa - 1u), 64);  // (nfa >= 1: the first group fits)
+                    if (fit_a && ca) {
+                        uint32_t qp = ia - ca;
+                        for (uint32_t m = ma; m; m &= m - 1u) queue[qp++] = (own_a << 26) | (base_a + (uint32_t)__builtin_ctz(m));
+                        ma = 0u;
                     }
-                    uint32_t qinst = 0u, win = slot;
-                    if (INST) qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
-                    bool cand = false;
-                    unsigned long long key = 0ull;
-                    if (act) {
-                        const float4 a = sc.tris[3 * (size_t)slot + 0];
-                        const float4 b = sc.tris[3 * (size_t)slot + 1];
-                        const float4 c = sc.tris[3 * (size_t)slot + 2];
-                        if (STATS) ++n_tris;
-                        f3 pos;
-                        float b1, b2;
-                        if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), qo, qd, pos, b1, b2)) {
-                            float d2;
-                            uint32_t prim;
-                            if (INST) {  // position back through Mat, distance in world space (primitive.cpp:38-43)
-                                const DevInstance& I = sc.insts[qinst];
-                                const uint32_t oc = wbase + owner;
-                                d2 = dist2(mk3(s_wray[0 * 256 + oc], s_wray[1 * 256 + oc], s_wray[2 * 256 + oc]), transform_point(I.mat, pos));
-                                prim = I.prim_base + __float_as_uint(a.w);
-                                win = I.virt_base + (slot - I.slot_base);
-                            } else {
-                                d2 = dist2(qo, pos);
-                                prim = __float_as_uint(a.w);
-                            }
-                            key = ((unsigned long long)__float_as_uint(d2) << 32) | prim;
-                            // NaN / inf d2 have bit patterns above FLT_MAX's: they can never win, as in the reference
-                            cand = true;
-                            atomicMin(&s_key[wbase + owner], key);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    for (uint32_t base = 0; base < T; base += 64u) {  // wave-uniform trip count
+                        const uint32_t kq = base + lane;
+                        const bool act = kq < T;
+                        const uint32_t item = ((volatile uint32_t*)queue)[act ? kq : 0u];
+                        const uint32_t owner = act ? (item >> 26) : lane;
+                        const uint32_t slot = item & 0x03FFFFFFu;
+                        f3 qo, qd;
+                        if (LEAN) {
+                            const uint32_t oc = wbase + owner;
+                            qo = mk3(s_lray[0 * 256 + oc], s_lray[1 * 256 + oc], s_lray[2 * 256 + oc]);
+                            qd = mk3(s_lray[3 * 256 + oc], s_lray[4 * 256 + oc], s_lray[5 * 256 + oc]);
+                        } else {
+                            qo = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
+                            qd = mk3(__shfl(ld.x, (int)owner, 64), __shfl(ld.y, (int)owner, 64), __shfl(ld.z, (int)owner, 64));
                         }
+                        uint32_t qinst = 0u, win = slot;
+                        if (INST) qinst = (uint32_t)__shfl((int)inst, (int)owner, 64);
+                        bool cand = false;
+                        unsigned long long key = 0ull;
+                        if (act) {
+                            const float4 a = sc.tris[3 * (size_t)slot + 0];
+                            const float4 b = sc.tris[3 * (size_t)slot + 1];
+                            const float4 c = sc.tris[3 * (size_t)slot + 2];
+                            if (STATS) ++n_tris;
+                            f3 pos;
+                            float b1, b2;
+                            if (triangle_hit_pos(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), qo, qd, pos, b1, b2)) {
+                                float d2;
+                                uint32_t prim;
+                                if (INST) {  // position back through Mat, distance in world space (primitive.cpp:38-43)
+                                    const DevInstance& I = sc.insts[qinst];
+                                    const uint32_t oc = wbase + owner;
+                                    d2 = dist2(mk3(s_wray[0 * 256 + oc], s_wray[1 * 256 + oc], s_wray[2 * 256 + oc]), transform_point(I.mat, pos));
+                                    prim = I.prim_base + __float_as_uint(a.w);
+                                    win = I.virt_base + (slot - I.slot_base);
+                                } else {
+                                    d2 = dist2(qo, pos);
+                                    prim = __float_as_uint(a.w);
+                                }
+                                key = ((unsigned long long)__float_as_uint(d2) << 32) | prim;
+                                // NaN / inf d2 have bit patterns above FLT_MAX's: they can never win, as in the reference
+                                cand = true;
+                                atomicMin(&s_key[wbase + owner], key);
+                            }
+                        }
+                        if (STATS && lane == 0) ++s_iters[4 + wv];
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = LEAN ? sc.n_prims + win : win;
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     }
-                    if (STATS && lane == 0) ++s_iters[4 + wv];
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (cand && ((volatile unsigned long long*)s_key)[wbase + owner] == key) s_slot[wbase + owner] = LEAN ? sc.n_prims + win : win;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
                 }
                 const unsigned long long won =
                     ((volatile unsigned long long*)s_key)[(STEAL && k >= 0xFFFFFF00u && k != 0xFFFFFFFFu) ? wbase + (k & 63u) : tid];
@@ -2101,7 +2136,6 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     tlimit = INST ? (limit_from_d2(best.d2, 0.0f) + padw4) * lscale + 4.0f * pad : limit_from_d2(best.d2, pad);
                 }
                 pending = false;  // everything that was queued has been tested
-                q_lanes = 0u;
             }
         }
         if (STATS) {
