@@ -373,7 +373,7 @@ def main():
         # measure_traversal ran on THIS rank's tiles, so the per-sample figures are already the local share; a launch is one
         # depth of one batch of `sif` samples: per launch = per sample x samples / launches
         per_launch = st.samples / st.intersect_launches
-        inst = "inst12_4waves" if args.config == "C5I" else ("lean8_5waves" if int(bvh.depth8) <= 9 else "deep15_4waves")
+        inst = r.kernel_instance()  # what prt_launch_traverse launches for this scene (one decision function, csrc/prt_kernels.hip)
         isa = isa_counts(inst)
         valu_alg = (node_wave_steps_sample * isa["node_step"] + tri_rounds_sample * isa["triangle_round"]) * per_launch
         achieved = valu_alg / (avg_ms * 1e-3) / 1e9
@@ -504,6 +504,8 @@ def main():
         secondary["C2"] = time_config(prt, torch, "C2", local_rank, 64, 3)
         secondary["C5"] = time_config(prt, torch, "C5", local_rank, 64, 2)
         secondary["C5I"] = time_config(prt, torch, "C5I", local_rank, 64, 2)
+        # BASELINE config 4 (the C3 scene at 3840x2160, 8 bounces; the config's 8 GPUs tile the frame, here the whole frame on one)
+        secondary["C4"] = time_config(prt, torch, "C4", local_rank, 16, 2)
         pre = presets_block(prt, torch, orc, local_rank, cores, min(5.0, args.cpu_seconds))
         secondary["RANDOM_BALLS_LARGE"] = {k: v for k, v in pre.items() if k != "cpu_linear_scan"}
         if cpu is not None and "cpu_linear_scan" in pre:

@@ -287,6 +287,10 @@ int prt_reset_stats(PrtContext* ctx);
 int prt_measure_traversal(PrtContext* ctx, uint32_t max_depth, uint32_t seed, uint32_t sample, PrtStats* out);
 int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
 int prt_kernel_occupancy(PrtContext* ctx, PrtOccupancy* out);
+/* Name of the traversal kernel instance the current scene and tunables select (what prt_render launches and what
+ * prt_kernel_occupancy describes): "lean8_5waves", "deep15_4waves", "inst12_4waves", "wide11_5waves", "bvh4", "bvh2".
+ * Written NUL-terminated into name[capacity].  The same decision function drives the launch (csrc/prt_kernels.hip). */
+int prt_kernel_instance(PrtContext* ctx, char* name, uint32_t capacity);
 /* Copies the built BVH out (host arrays): nodes n_nodes*16 floats (layout: csrc/bvh.h), tris
  * n_triangles*12 floats in leaf order.  Either pointer may be NULL.  Works on host-only contexts. */
 int prt_bvh_read(PrtContext* ctx, float* nodes, float* tris);

@@ -148,6 +148,7 @@ SIGNATURES = {
     "prt_measure_traversal": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PrtStats)]),
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_kernel_occupancy": (C.c_int, [_vp, C.POINTER(PrtOccupancy)]),
+    "prt_kernel_instance": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),
     "prt_bvh_read4": (C.c_int, [_vp, _fp]),

@@ -1480,7 +1480,7 @@ int prt_kernel_occupancy(PrtContext* c, PrtOccupancy* out) {
     if (!out) return PRT_ERR_INVALID;
     if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
     int nb = 0, vg = 0, sg = 0, lds = 0;
-    if (prt_traverse_occupancy(c->dsc, &nb, &vg, &sg, &lds)) return fail(c, PRT_ERR_HIP, "occupancy query failed");
+    if (prt_traverse_occupancy(c->dsc, c->tune, &nb, &vg, &sg, &lds)) return fail(c, PRT_ERR_HIP, "occupancy query failed");
     hipDeviceProp_t prop;
     HIPCHECK(c, hipGetDeviceProperties(&prop, c->device));
     out->blocks_per_cu = (uint32_t)nb;
@@ -1489,8 +1489,15 @@ int prt_kernel_occupancy(PrtContext* c, PrtOccupancy* out) {
     out->vgprs = (uint32_t)vg;
     out->lds_bytes_per_block = (uint32_t)lds;
     out->compute_units = (uint32_t)prop.multiProcessorCount;
-    out->resident_grid_blocks = (c->dsc.nodes8 && !c->dsc.n_insts && (c->dsc.depth8 <= 9u || c->dsc.nodes4) && c->tune.stack_lds == 0u)
+    out->resident_grid_blocks = !strcmp(prt_traverse_instance(c->dsc, c->tune), "lean8_5waves")
                                     ? c->tune.grid_blocks + c->tune.grid_blocks / 4u : c->tune.grid_blocks;
+    return PRT_OK;
+}
+
+int prt_kernel_instance(PrtContext* c, char* name, uint32_t capacity) {
+    if (!c || !name || capacity == 0u) return PRT_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    snprintf(name, capacity, "%s", prt_traverse_instance(c->dsc, c->tune));
     return PRT_OK;
 }
 

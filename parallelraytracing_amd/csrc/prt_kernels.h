@@ -135,7 +135,9 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
                          const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary = nullptr);
 // true if prt_launch_traverse would run the instance that can rebuild compact primary rays (and needs no overflow list)
 bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune);
-int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes);
+int prt_traverse_occupancy(const DevScene& sc, const PrtTravTuning& tune, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes);
+// name of the traversal kernel instance prt_launch_traverse runs for this scene / these tunables (as tools/isa_count.py names them)
+const char* prt_traverse_instance(const DevScene& sc, const PrtTravTuning& tune);
 void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                           uint32_t max_rays, int stack_depth, int variant, unsigned long long* stats);
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,

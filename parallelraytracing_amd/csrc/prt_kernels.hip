@@ -1554,27 +1554,6 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
 #else
 #define T8_SEL(M, A, B) ((M) ? (A) : (B))
 #endif
-// how a child's hit bits enter the mask.  0: compare + select (the compiler emits v_cmp -> vcc, v_cndmask_b32_e32);
-// 1: the same compare into an SGPR pair and the VOP3 select on it (A/B: the vcc form of v_cndmask measured 4x the issue
-// cost of the SGPR-pair form in isolation, profiles/r2_issue_rate.txt); 2: sign of tf - tn, no compare (tf - tn has the
-// exact sign of the comparison; a NaN from inf - inf counts as a hit, which is the conservative side)
-#ifndef PRT_T8_HITSEL
-#define PRT_T8_HITSEL 0
-#endif
-#if PRT_T8_HITSEL == 1
-#define T8_HIT(TN, TF, CB)                                                                       \
-    {                                                                                            \
-        unsigned long long hm_;                                                                  \
-        uint32_t hv_;                                                                            \
-        asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(hm_) : "v"(TN), "v"(TF));                       \
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hv_) : "v"(CB), "s"(hm_));                  \
-        hitmask |= hv_;                                                                          \
-    }
-#elif PRT_T8_HITSEL == 2
-#define T8_HIT(TN, TF, CB) hitmask |= (CB) & ~(uint32_t)((int32_t)__float_as_uint((TF) - (TN)) >> 31);
-#else
-#define T8_HIT(TN, TF, CB) hitmask |= ((TN) <= (TF)) ? (CB) : 0u;
-#endif
 #define T8_CHILD(J, NX, FX, NY, FY, NZ, FZ)                                                                          \
     {                                                                                                                \
         const float tnx = __builtin_fmaf((float)(((NX) >> (8 * J)) & 0xFFu), Ax, Bnx);                               \
@@ -1586,7 +1565,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));                     \
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlimit));                   \
         const uint32_t cb = ((bits4 >> (8 * J)) & 0xFFu) << ((idx4 >> (8 * J)) & 0xFFu);                             \
-        T8_HIT(tn, tf, cb)                                                                                           \
+        hitmask |= (tn <= tf) ? cb : 0u;                                                                             \
     }
 #define T8_HALF(META4, NX, FX, NY, FY, NZ, FZ)                                                                       \
     {                                                                                                                \
@@ -1973,66 +1952,72 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         // an atomic and without a per-triangle loop in the node step.
         uint32_t q_groups = 0u;
         while (walk) {
-            // current group: G while it has pending internal hits, else the top of the stack (read unconditionally)
-            const int spr = sp > 0 ? sp - 1 : 0;
-            const uint2 top = s_stack[spr * 256 + tid];
-            const bool has = gy > 0x00FFFFFFu;
-            if (INST) {
-                const bool enter = !in_blas && ipm != 0u;               // instance hits of the last top-level node first
-                const bool leave = in_blas && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
-                if (enter || leave) {  // level switches are done by the whole wave together, next to the refill
-                    stall = true;
-                    walk = false;
-                    if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_groups >= tri_min) break;
-                    continue;
-                }
-            }
-            const uint32_t cx = has ? gx : top.x;
-            uint32_t cy = has ? gy : top.y;
-            sp = has ? sp : spr;
-            const uint32_t bit = 31u - (uint32_t)__builtin_clz(cy);  // highest pending hit: bits 24..31
-            cy &= ~(1u << bit);
-            s_stack[sp * 256 + tid] = make_uint2(cx, cy);  // the remaining siblings (kept only if there are any)
-            sp += (cy > 0x00FFFFFFu) ? 1 : 0;
-            const uint32_t slot = (bit - 24u) ^ (octinv4 & 7u);
-            const uint32_t idx = cx + (uint32_t)__popc(cy & ((1u << slot) - 1u));  // bits 0..7 of cy: imask
-            const uint4* nb = sc.nodes8 + (size_t)sc.node_stride * idx;
-            const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
-            if (STATS) {
-                ++n_nodes;
-                ++ray_steps;
-                if (ray_steps > ray_steps_max) ray_steps_max = ray_steps;
-                if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[wv];
-                if ((uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-            }
-            T8_BOXTEST()
-            gx = w1.x;
-            gy = (hitmask & 0xFF000000u) | (eim >> 24);
-            uint32_t tm = hitmask & 0x00FFFFFFu;
-            if (sp > stack_cap) {  // give the ray up; it is re-traversed through the overflow list
-                overflow = true;
-                gy = 0u;
-                sp = 0;
-                tm = 0u;
+            uint32_t tm = 0u, tb = 0u;
+            {
+                // current group: G while it has pending internal hits, else the top of the stack (read unconditionally)
+                const int spr = sp > 0 ? sp - 1 : 0;
+                const uint2 top = s_stack[spr * 256 + tid];
+                const bool has = gy > 0x00FFFFFFu;
+                bool level_switch = false;
                 if (INST) {
-                    ipm = 0u;
-                    in_blas = false;
+                    const bool enter = !in_blas && ipm != 0u;               // instance hits of the last top-level node first
+                    const bool leave = in_blas && !has && top.x == T8_SENTINEL;  // the instance's tree is exhausted
+                    if (enter || leave) {  // level switches are done by the whole wave together, next to the refill
+                        stall = true;
+                        walk = false;
+                        level_switch = true;
+                    }
                 }
-            } else if (INST && !in_blas) {  // top-level node: its "triangles" are instances, entered one by one
-                ipb = w1.y;
-                ipm = tm;
-                tm = 0u;
+                if (!level_switch) {
+                    const uint32_t cx = has ? gx : top.x;
+                    uint32_t cy = has ? gy : top.y;
+                    sp = has ? sp : spr;
+                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(cy);  // highest pending hit: bits 24..31
+                    cy &= ~(1u << bit);
+                    s_stack[sp * 256 + tid] = make_uint2(cx, cy);  // the remaining siblings (kept only if there are any)
+                    sp += (cy > 0x00FFFFFFu) ? 1 : 0;
+                    const uint32_t slot = (bit - 24u) ^ (octinv4 & 7u);
+                    const uint32_t idx = cx + (uint32_t)__popc(cy & ((1u << slot) - 1u));  // bits 0..7 of cy: imask
+                    const uint4* nb = sc.nodes8 + (size_t)sc.node_stride * idx;
+                    const uint4 w0 = nb[0], w1 = nb[1], w2 = nb[2], w3 = nb[3], w4 = nb[4];
+                    if (STATS) {
+                        ++n_nodes;
+                        ++ray_steps;
+                        if (ray_steps > ray_steps_max) ray_steps_max = ray_steps;
+                        if ((int)lane == __ffsll((long long)__ballot(true)) - 1) ++s_iters[wv];
+                        if ((uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+                    }
+                    T8_BOXTEST()
+                    gx = w1.x;
+                    gy = (hitmask & 0xFF000000u) | (eim >> 24);
+                    tm = hitmask & 0x00FFFFFFu;
+                    tb = w1.y;
+                    if (sp > stack_cap) {  // give the ray up; it is re-traversed through the overflow list
+                        overflow = true;
+                        gy = 0u;
+                        sp = 0;
+                        tm = 0u;
+                        if (INST) {
+                            ipm = 0u;
+                            in_blas = false;
+                        }
+                    } else if (INST && !in_blas) {  // top-level node: its "triangles" are instances, entered one by one
+                        ipb = tb;
+                        ipm = tm;
+                        tm = 0u;
+                    }
+                    walk = (gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u);
+                }
             }
             const unsigned long long qm = __ballot(tm != 0u);
             if (tm != 0u) {
                 const uint32_t own = (STEAL && k >= 0xFFFFFF00u) ? (k & 63u) : lane;  // a helper's tests belong to its root
                 const uint32_t pos = q_groups + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
-                ((uint2*)queue)[pos] = make_uint2(w1.y, (own << 24) | tm);
+                ((uint2*)queue)[pos] = make_uint2(tb, (own << 24) | tm);
                 s_qn[wv] = q_groups + (uint32_t)__popcll(qm);  // (the same value from every queueing lane)
                 pending = true;
             }
             q_groups += (uint32_t)__popcll(qm);
-            walk = (gy > 0x00FFFFFFu) || sp > 0 || (INST && ipm != 0u);
             if ((uint32_t)__popcll(__ballot(walk)) <= tune.exit_max || q_groups >= tri_min) break;
         }
         if (STATS) {
@@ -2489,6 +2474,32 @@ bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune) {
            tune.stack_cap == 0u && sc.depth8 <= 9u;
 }
 
+// Which traversal kernel instance prt_launch_traverse runs for this scene and these tunables: ONE decision, shared by the
+// launch, the occupancy report and prt_kernel_instance (bench.py names the instance in its line and takes the loops'
+// static instruction counts of exactly that instance).
+//   inst12_4waves  placed mesh copies: two-level walk, 12 stack entries, 4 waves per SIMD
+//   wide11_5waves  A/B (stack_lds = 5): 11 entries, 5 waves per SIMD, ray and best hit in registers
+//   lean8_5waves   default: 8 entries, 5 waves per SIMD (ray and best hit in LDS); trees of <= 9 levels, and deeper
+//                  HOST-built trees, whose rare deeper rays go through the overflow list to the 4-wide tree (C5)
+//   deep15_4waves  deeper trees without a 4-wide fallback (device-built): 15 entries, 4 waves per SIMD
+enum PrtT8Kind { T8_NONE = 0, T8_INST12_4, T8_WIDE11_5, T8_LEAN8_5, T8_DEEP15_4 };
+static PrtT8Kind t8_kind(const DevScene& sc, const PrtTravTuning& tune) {
+    if (!((tune.wide == 2u || sc.n_insts || !sc.nodes4) && sc.nodes8)) return T8_NONE;
+    if (sc.n_insts) return T8_INST12_4;
+    if (tune.stack_lds == 5u) return T8_WIDE11_5;
+    const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && (sc.depth8 <= 9u || sc.nodes4 != nullptr));
+    return lean ? T8_LEAN8_5 : T8_DEEP15_4;
+}
+const char* prt_traverse_instance(const DevScene& sc, const PrtTravTuning& tune) {
+    switch (t8_kind(sc, tune)) {
+        case T8_INST12_4: return "inst12_4waves";
+        case T8_WIDE11_5: return "wide11_5waves";
+        case T8_LEAN8_5: return "lean8_5waves";
+        case T8_DEEP15_4: return "deep15_4waves";
+        default: return tune.wide ? "bvh4" : "bvh2";
+    }
+}
+
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
                          const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary) {
@@ -2517,7 +2528,8 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((KERNEL<L, W, MODE, false>), GRID, block, 0, st, sc, in.o, in.d, in.hit, in.hd2,    \
                                COUNT, work, spill, LIST, ovf, tune, stats);                                        \
     } while (0)
-    if ((tune.wide == 2u || sc.n_insts || !sc.nodes4) && sc.nodes8) {  // (device-built scenes only have the 8-wide tree)
+    const PrtT8Kind kind = t8_kind(sc, tune);
+    if (kind != T8_NONE) {  // (device-built scenes only have the 8-wide tree)
         // default: compressed 8-wide tree; a ray needs at most depth8 - 1 stacked node groups.  15 entries at
         // 4 waves/SIMD or 11 entries at 5 waves/SIMD (tune.stack_lds == 5); deeper rays take the overflow list.
 #define PRT_LAUNCH_8(L, W, IN)                                                                                     \
@@ -2529,7 +2541,7 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, false, IN>), grid, block, 0, st, sc, in.o, in.d,      \
                                in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{});                   \
     } while (0)
-        if (sc.n_insts) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths).
+        if (kind == T8_INST12_4) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths).
             // 12 stack entries + the lanes' world rays in LDS = the same 40 KB per block as the one-level instance
             PRT_LAUNCH_8(12, 4, true);
             return;
@@ -2539,11 +2551,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
         // force one for A/B runs
         // (deeper host-built trees: rays that need more than 8 entries go through the overflow list to the 4-wide
         // spill-capable instance; C5, 11 levels: deepest stack 8, no such ray)
-        const bool lean = tune.stack_lds == 6u || (tune.stack_lds == 0u && (sc.depth8 <= 9u || sc.nodes4 != nullptr));
-        const uint32_t stack_l = tune.stack_lds == 5u ? 11u : lean ? 8u : 15u;
-        if (tune.stack_lds == 5u) {
+        const uint32_t stack_l = kind == T8_WIDE11_5 ? 11u : kind == T8_LEAN8_5 ? 8u : 15u;
+        if (kind == T8_WIDE11_5) {
             PRT_LAUNCH_8(11, 5, false);
-        } else if (lean) {
+        } else if (kind == T8_LEAN8_5) {
             const dim3 grid5(g == tune.grid_blocks ? g + g / 4u : g);  // 5 instead of 4 resident blocks per CU
             PrtTravTuning t5 = tune;
             if (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u) t5.steal = 0u;  // (a helper cannot hand a ray to the overflow list)
@@ -2607,11 +2618,13 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 // Static occupancy of the default traversal kernel instance for this scene (what the wavefront-occupancy figure of
 // the bench line is computed from): resident 256-thread blocks per CU by the runtime's occupancy calculator, and the
 // kernel's register / LDS footprint.
-int prt_traverse_occupancy(const DevScene& sc, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes) {
-    const void* fn = sc.n_insts ? (const void*)k_traverse8_persistent<12, 4, false, true>
-                     : (sc.nodes8 && (sc.depth8 <= 9u || sc.nodes4)) ? (const void*)k_traverse8_persistent<8, 5, false, false, true>
-                     : sc.nodes8 ? (const void*)k_traverse8_persistent<15, 4, false, false>
-                                 : (const void*)k_traverse4_persistent<32, 4, 3, false>;
+int prt_traverse_occupancy(const DevScene& sc, const PrtTravTuning& tune, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes) {
+    const PrtT8Kind kind = t8_kind(sc, tune);
+    const void* fn = kind == T8_INST12_4 ? (const void*)k_traverse8_persistent<12, 4, false, true>
+                     : kind == T8_WIDE11_5 ? (const void*)k_traverse8_persistent<11, 5, false, false>
+                     : kind == T8_LEAN8_5 ? (const void*)k_traverse8_persistent<8, 5, false, false, true>
+                     : kind == T8_DEEP15_4 ? (const void*)k_traverse8_persistent<15, 4, false, false>
+                                           : (const void*)k_traverse4_persistent<32, 4, 3, false>;
     hipFuncAttributes at;
     hipError_t e = hipFuncGetAttributes(&at, fn);
     if (e != hipSuccess) return (int)e;

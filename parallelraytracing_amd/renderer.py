@@ -453,6 +453,12 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_kernel_occupancy(self._ctx, C.byref(o)))
         return o
 
+    def kernel_instance(self) -> str:
+        """Name of the traversal kernel instance the scene and tunables select (prt_kernel_instance)."""
+        buf = C.create_string_buffer(64)
+        self._check(capi.lib().prt_kernel_instance(self._ctx, buf, 64))
+        return buf.value.decode()
+
     def bvh_read(self):
         b = self.bvh_info()
         nodes = np.zeros((b.n_nodes, 16), np.float32)

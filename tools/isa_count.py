@@ -10,7 +10,7 @@ default instance of k_traverse8_persistent (and the other instances bench.py can
 find the loops (a branch to an earlier label closes one) and pick
   * the node loop  = the largest loop that holds the five 16-B loads of an 80-B node and the v_cvt_f32_ubyte
                      conversions of its quantized planes, and no IEEE division,
-  * the triangle loop = the largest loop that holds IEEE divisions (v_div_fmas_f32: Triangle::Intersect) and the
+  * the triangle loop = the INNERMOST loop that holds IEEE divisions (v_div_fmas_f32: Triangle::Intersect) and the
                      three loads of a triangle record, and no plane conversion.
 Counts are of ALL instructions between the loop's first label and its back edge (rarely taken side blocks such as the
 overflow path included: an upper bound of what one trip issues, within a few per cent).
@@ -30,7 +30,8 @@ CSRC = os.path.join(ROOT, "parallelraytracing_amd", "csrc")
 INSTANCES = {
     "lean8_5waves": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb0EE",        # default: trees of <= 9 levels (C2, C3, C4)
     "lean8_5waves_primary": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb1EE",  # the same reading compact primary rays (bounce 0)
-    "deep15_4waves": "k_traverse8_persistentILi15ELi4ELb0ELb0ELb0ELb0EE",       # deeper trees (C5)
+    "deep15_4waves": "k_traverse8_persistentILi15ELi4ELb0ELb0ELb0ELb0EE",       # deeper device-built trees (no 4-wide fallback)
+    "wide11_5waves": "k_traverse8_persistentILi11ELi5ELb0ELb0ELb0ELb0EE",       # A/B (stack_lds = 5)
     "inst12_4waves": "k_traverse8_persistentILi12ELi4ELb0ELb1ELb0ELb0EE",       # placed copies (C5I)
 }
 
@@ -100,15 +101,17 @@ def count(lines, lo, hi):
     return c
 
 
-def pick(lines, lps, need, forbid):
+def pick(lines, lps, need, forbid, smallest=False):
     """The LARGEST loop that has the `need` signature and nothing of `forbid`: a source loop with `continue`s and
-    several exits compiles to nested back edges to neighbouring headers; the outermost of them is the whole body."""
+    several exits compiles to nested back edges to neighbouring headers; the outermost of them is the whole body.
+    smallest=True picks the INNERMOST such loop instead (the triangle rounds sit inside the phase's pass loops, which
+    also expand the queued groups: a round is the inner loop)."""
     best = None
     for lo, hi in lps:
         body = lines[lo:hi + 1]
         if all(sum(1 for l in body if l.startswith(p)) >= n for p, n in need.items()) and \
                 not any(l.startswith(forbid) for l in body):
-            if best is None or hi - lo > best[1] - best[0]:
+            if best is None or (hi - lo < best[1] - best[0] if smallest else hi - lo > best[1] - best[0]):
                 best = (lo, hi)
     return best
 
@@ -130,7 +133,7 @@ def main():
             continue
         lps = loops(lines)
         node = pick(lines, lps, {"global_load_dwordx4": 5, "v_cvt_f32_ubyte": 24}, "v_div_fmas_f32")
-        tri = pick(lines, lps, {"v_div_fmas_f32": 3, "global_load_dword": 3}, "v_cvt_f32_ubyte")
+        tri = pick(lines, lps, {"v_div_fmas_f32": 3, "global_load_dword": 3}, "v_cvt_f32_ubyte", smallest=True)
         entry = {"function_instructions": sum(1 for l in lines if not l.endswith(":"))}
         if node:
             entry["node_step"] = count(lines, *node)
