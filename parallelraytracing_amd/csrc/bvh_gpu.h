@@ -23,3 +23,10 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
 // their own: every instance then gets a leaf to itself).
 int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
                             uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out, float leaf_cost = 0.0f);
+
+// Measurement aid (prt_set_param("sort_rays", 1 | 2)): idx2[0..n) = the order of rays 0..n-1 by (Morton cell of the origin
+// in a 32^3 grid over [bmin, bmax], direction octant) (mode 1) or (octant, cell) (mode 2).  keys, keys2, idx, idx2: n
+// uint32 each; temp: prt_sort_rays_temp_bytes(n) bytes.
+size_t prt_sort_rays_temp_bytes(uint32_t n);
+int prt_sort_rays(hipStream_t st, const float4* ro, const float4* rd, uint32_t n, const float bmin[3], const float bmax[3],
+                  uint32_t mode, uint32_t* keys, uint32_t* keys2, uint32_t* idx, uint32_t* idx2, void* temp, size_t temp_bytes);

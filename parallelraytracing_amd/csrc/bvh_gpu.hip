@@ -1035,3 +1035,44 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
     return 0;
 #undef GB_TRY
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Measurement aid, not on the default path (prt_set_param("sort_rays", 1 | 2), tools/sort_ab.py; the round-2 review asked
+// for ray binning to be measured on the memory-bound 10 M-triangle config): order of a bounce's front rays by the cell of
+// their origin in a 32^3 grid over the BVH's root box (Morton order) and their direction octant.  The traversal kernel
+// then takes its rays through the permutation; nothing is moved.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_ray_keys(const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, float3 bmin, float3 binv,
+                           uint32_t mode, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 O = ro[i], D = rd[i];
+    const float c[3] = {(O.x - bmin.x) * binv.x, (O.y - bmin.y) * binv.y, (O.z - bmin.z) * binv.z};
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) q[a] = (uint32_t)fminf(fmaxf(c[a] * 32.0f, 0.0f), 31.0f);
+    const uint32_t cell = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);  // 15 bits
+    const uint32_t oct = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
+    keys[i] = mode == 2u ? (oct << 15) | cell : (cell << 3) | oct;
+    idx[i] = i;
+}
+}  // namespace
+
+size_t prt_sort_rays_temp_bytes(uint32_t n) {
+    size_t temp_bytes = 0;
+    uint32_t* p = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, p, p, p, p, n, 0, 18, (hipStream_t)0) != hipSuccess) return 0;
+    return temp_bytes;
+}
+
+int prt_sort_rays(hipStream_t st, const float4* ro, const float4* rd, uint32_t n, const float bmin[3], const float bmax[3],
+                  uint32_t mode, uint32_t* keys, uint32_t* keys2, uint32_t* idx, uint32_t* idx2, void* temp, size_t temp_bytes) {
+    if (n == 0) return 0;
+    const float3 mn = make_float3(bmin[0], bmin[1], bmin[2]);
+    const float3 inv = make_float3(1.0f / fmaxf(bmax[0] - bmin[0], 1e-20f), 1.0f / fmaxf(bmax[1] - bmin[1], 1e-20f),
+                                   1.0f / fmaxf(bmax[2] - bmin[2], 1e-20f));
+    hipLaunchKernelGGL(k_ray_keys, dim3((n + 255u) / 256u), dim3(256), 0, st, ro, rd, n, mn, inv, mode, keys, idx);
+    GB_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, idx, idx2, n, 0, 18, st));
+    return 0;
+}

@@ -112,7 +112,10 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 1u};
+    uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
+    uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage
+    size_t sort_entries = 0, sort_temp = 0;
     uint32_t* h_counts = nullptr;  // pinned: the front / back ray counts of each bounce as the host learns them
     hipEvent_t ev_counts[PRT_MAX_DEPTH + 2] = {};
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
@@ -337,7 +340,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     if (compact && c->pix_entries < c->tm.n_pix_local) {
         free_dev(c->d_pix);
         c->pix_entries = 0;
-        HIPCHECK(c, hipMalloc((void**)&c->d_pix, 2 * (size_t)c->tm.n_pix_local * sizeof(float4)));
+        HIPCHECK(c, hipMalloc((void**)&c->d_pix, 4 * (size_t)c->tm.n_pix_local * sizeof(float4)));
         c->pix_entries = c->tm.n_pix_local;
     }
     const PrtPrimary primary{(const uint32_t*)c->rb[0].t, c->d_pix, {c->cam.pos.x, c->cam.pos.y, c->cam.pos.z}, c->tm.n_pix_local,
@@ -356,6 +359,33 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             if (c->variant == 0 || c->dsc.n_insts || !c->dsc.nodes) {  // placed copies / device-built trees: the 8-wide kernel only
                 PrtTravTuning tune = c->tune;
                 tune.probe_slot = d;
+                tune.perm = nullptr;
+                if (c->sort_rays && !(compact && d == 0) && (d > 0 || c->sampling.jitter)) {
+                    // measurement aid (tools/sort_ab.py): the host needs the ray count, so this path synchronises; the sort
+                    // is timed as its own stage (scan_ms), the traversal that follows as usual
+                    uint32_t n_front = 0;
+                    HIPCHECK(c, hipMemcpyAsync(&n_front, front_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                    HIPCHECK(c, hipStreamSynchronize(c->stream));
+                    if (n_front > 1u) {
+                        if (c->sort_entries < n_paths) {
+                            free_dev(c->d_sort);
+                            c->sort_entries = 0;
+                            c->sort_temp = prt_sort_rays_temp_bytes(n_paths);
+                            HIPCHECK(c, hipMalloc((void**)&c->d_sort, 4 * (size_t)n_paths * sizeof(uint32_t) + c->sort_temp));
+                            c->sort_entries = n_paths;
+                        }
+                        EventPair es{};
+                        HIPCHECK(c, hipEventSynchronize(ep.a));  // (the traversal's start event is re-recorded after the sort)
+                        if ((rc = begin_event(c, 4, &es))) return rc;
+                        uint32_t* q = c->d_sort;
+                        if (prt_sort_rays(c->stream, in.o, in.d, n_front, c->dsc.root_min, c->dsc.root_max, c->sort_rays, q, q + n_paths,
+                                          q + 2 * (size_t)n_paths, q + 3 * (size_t)n_paths, q + 4 * (size_t)n_paths, c->sort_temp))
+                            return fail(c, PRT_ERR_HIP, "ray sort failed");
+                        if ((rc = end_event(c, &es))) return rc;
+                        if (c->timing) HIPCHECK(c, hipEventRecord(ep.a, c->stream));
+                        tune.perm = q + 3 * (size_t)n_paths;
+                    }
+                }
                 prt_launch_traverse(c->stream, c->dsc, in, front_count, c->d_work, c->d_spill, n_paths, c->bvh.max_depth,
                                     c->bvh.max_stack4, tune, trav_stats, (compact && d == 0) ? &primary : nullptr);
             }
@@ -363,6 +393,15 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
                 prt_launch_intersect(c->stream, c->dsc, in, front_count, n_paths, stack_depth, c->variant, trav_stats);
             if ((rc = end_event(c, &ep))) return rc;
             ++c->stats.intersect_launches;
+            if (compact && d == 0) {
+                if (c->tune.primary_hit) {  // (timed with the shade stage)
+                    if ((rc = begin_event(c, 2, &ep))) return rc;
+                    prt_launch_primary_hit(c->stream, c->dsc, primary, in.hit, c->d_pix);
+                    if ((rc = end_event(c, &ep))) return rc;
+                } else {  // A/B: "no record" for every pixel (hit id 0xFFFFFFFF never equals a hit k_shade looks up)
+                    HIPCHECK(c, hipMemsetAsync(c->d_pix + 2 * (size_t)c->tm.n_pix_local, 0xFF, 2 * (size_t)c->tm.n_pix_local * sizeof(float4), c->stream));
+                }
+            }
         }
         uint32_t n_rays_known = 0xFFFFFFFFu;
         if (exact) {
@@ -583,6 +622,7 @@ void prt_destroy(PrtContext* c) {
         free_dev(c->d_work);
         free_dev(c->d_pix);
         free_dev(c->d_spill);
+        free_dev(c->d_sort);
         free_dev(c->d_scratch);
         for (EventPair& ep : c->events) {
             (void)hipEventDestroy(ep.a);
@@ -1542,6 +1582,8 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "stack_lds" && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 24 || value == 39)) c->tune.stack_lds = (uint32_t)value;
     else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
     else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
+    else if (n == "primary_hit" && (value == 0 || value == 1)) c->tune.primary_hit = (uint32_t)value;
+    else if (n == "sort_rays" && value >= 0 && value <= 2) c->sort_rays = (uint32_t)value;
     else if (n == "compact_primary" && (value == 0 || value == 1)) c->compact_primary = value;
     else if (n == "node_stride" && (value == 0 || value == 5 || value == 8)) c->node_stride = value;
     else if (n == "pad_log2" && value >= 8 && value <= 22) c->pad_coeff = std::ldexp(1.0f, -value);

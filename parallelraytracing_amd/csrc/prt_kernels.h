@@ -91,6 +91,8 @@ struct PrtTravTuning {
     uint32_t steal;        // 8-wide kernel at 5 waves/SIMD: a draining wave with at least this many idle lanes lets them take pending subtrees of its remaining rays (0 = off)
     uint32_t tail;         // 8-wide kernel: the last `tail` 64-ray granules per resident wave are handed out one at a time
     uint32_t probe_slot;   // instrumented instance only: this launch's timeline goes to stats[16 + 8 * probe_slot ..] (see PRT_TIMELINE)
+    const uint32_t* perm;  // measurement aid (sort_rays): the 8-wide kernel takes ray perm[i] where it would take ray i (nullptr = identity)
+    uint32_t primary_hit;  // host: with compact primary rays, rebuild the primary hit's surface interaction once per pixel (k_primary_hit); 0 = per sample in k_shade (A/B)
 };
 
 // Timeline of one launch of the instrumented 8-wide kernel, in s_memrealtime ticks (100 MHz), 8 words per launch:
@@ -116,7 +118,9 @@ struct PrtRayBuf {
 struct PrtPrimary {
     const uint32_t* pid;  // path id per ray slot
     const float4* pix;    // per local pixel: camera-ray direction, pixel index y * W + x (bits); then n_pix_local more records:
-                          // what the pixel's paths deliver if they end with their primary ray (read by k_accumulate)
+                          // what the pixel's paths deliver if they end with their primary ray (read by k_accumulate; for
+                          // pixels whose paths go on: x = ray slot of the first stored sample); then 2 x n_pix_local more:
+                          // the primary hit's surface interaction (k_primary_hit): {position, hit id}, {normal, material | front << 31}
     float origin[3];      // camera position
     uint32_t n_pix_local;
     float inv_n;          // 1 / n_pix_local (first guess of path id / n_pix_local, corrected exactly)
@@ -143,6 +147,9 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
                       uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary = nullptr);
+// compact primary rays: per-pixel surface interaction of the primary hit (records 2n.. and 3n.. of `pix`), between the
+// first traversal and the first k_shade of a batch
+void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats,
                            const float4* pix_end = nullptr);

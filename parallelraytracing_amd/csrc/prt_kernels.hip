@@ -157,7 +157,7 @@ PRT_DEV bool tile_pixel(const PrtTileMap& tm, uint32_t pl, uint32_t& x, uint32_t
 
 // The primary ray of path i (no jitter: the pixel centre, cpu/renderer.cpp:45) as k_raygen computed it for the path's
 // pixel (PrtPrimary, prt_kernels.h): path id -> (sample, local pixel) -> the pixel's record.
-PRT_DEV void primary_ray(const PrtPrimary& pr, uint32_t i, f3& o, f3& d, uint32_t& pixel, uint32_t& sample) {
+PRT_DEV void primary_ray(const PrtPrimary& pr, uint32_t i, f3& o, f3& d, uint32_t& pixel, uint32_t& sample, uint32_t* local_pixel = nullptr) {
     uint32_t q = (uint32_t)((float)i * pr.inv_n);  // within one of i / n_pix_local
     uint32_t r = i - q * pr.n_pix_local;
     if ((int32_t)r < 0) {
@@ -169,6 +169,7 @@ PRT_DEV void primary_ray(const PrtPrimary& pr, uint32_t i, f3& o, f3& d, uint32_
         r -= pr.n_pix_local;
     }
     sample = q;
+    if (local_pixel) *local_pixel = r;
     const float4 P = pr.pix[r];
     o = mk3(pr.origin[0], pr.origin[1], pr.origin[2]);
     d = mk3(P.x, P.y, P.z);
@@ -210,10 +211,13 @@ PRT_DEV float4 path_result(f3 L, float clamp, uint32_t depth) {
     return make_float4(L.x, L.y, L.z, __uint_as_float(depth));
 }
 
-template <int BUDGET, bool INST, bool ABVH, int BLOCK>
+// PRE: (pre_a, pre_b) = the hit record k_primary_hit computed for this path's pixel: {position, hit id}, {normal, material
+// | front face << 31}.  It replaces world_hit_from_id for the first segment when it was computed for the same hit id (it
+// always was: all samples of a pixel trace the same primary ray; the comparison keeps the kernel correct by itself).
+template <int BUDGET, bool INST, bool ABVH, int BLOCK, bool PRE = false>
 PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr, uint32_t& rng, uint32_t& depth,
                          uint32_t max_depth, const PrtSampling& sp, float4* __restrict__ rad_slot, uint32_t& id0,
-                         float& d2_0) {
+                         float& d2_0, float4 pre_a = float4{0.f, 0.f, 0.f, 0.f}, float4 pre_b = float4{0.f, 0.f, 0.f, 0.f}) {
 #pragma unroll
     for (int it = 0; it <= BUDGET; ++it) {
         if (id == HIT_MISS) {  // the miss branch of IntersectClosestKernel, renderer.cu:263-271
@@ -231,7 +235,14 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             return 2;
         }
         WorldHit w;
-        world_hit_from_id<INST>(sc, id, o, d, w);
+        if (PRE && it == 0 && __float_as_uint(pre_a.w) == id) {
+            w.pos = mk3(pre_a.x, pre_a.y, pre_a.z);
+            w.normal = mk3(pre_b.x, pre_b.y, pre_b.z);
+            w.material = __float_as_uint(pre_b.w) & 0x7FFFFFFFu;
+            w.front = (__float_as_uint(pre_b.w) >> 31) != 0u;
+        } else {
+            world_hit_from_id<INST>(sc, id, o, d, w);
+        }
         const uint32_t type = sc.mat_type[w.material];
         const float4 rgbs = sc.mat_rgbs[w.material];
         f3 atten, emitted, so, sd;
@@ -327,6 +338,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
         uint32_t stride = 0, base = 0;
         const uint32_t slot0 = block_alloc2<PRODUCER_BLOCK>(front, back, false, &CNT_A(counts, 0), &CNT_B(counts, 0),
                                                             &CNT_C(counts, 0), n_paths, s1 - s0, &stride, &base);
+        uint32_t first_slot = slot0;  // slot of this pixel's sample s0
         if (s1 - s0 < 8u) {
             // few samples per pixel in this batch (interactive use: ProgressiveRender adds ONE sample per call): SAMPLE-major
             // slots, every thread stores its own pixel's copies, coalesced across the pixels of a wave
@@ -357,6 +369,7 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             uint32_t first = 0u;
             if (front) first = base + (slot0 - base) * mult;
             if (back) first = n_paths - 1u - (base + ((n_paths - 1u - slot0) - base) * mult);
+            first_slot = first;
             const uint32_t lane = lane_id();
             for (unsigned long long m = __ballot(stored); m; m &= m - 1ull) {
                 const int p = __builtin_ctzll(m);
@@ -394,8 +407,9 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             if (COMPACT) {
                 // whether the pixel's paths end with their primary ray, and with what, is the same for all its samples: one
                 // record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
+                // (x of a "they go on" record: the ray slot of the pixel's first stored sample, for k_primary_hit)
                 if (in_range && blockIdx.y == 0)
-                    pix[tm.n_pix_local + pl] = stored ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
+                    pix[tm.n_pix_local + pl] = stored ? make_float4(__uint_as_float(first_slot), 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
             } else if (in_range && !stored) {
                 // the path ended with its primary ray (sky / light seen directly), or there is none
                 for (uint32_t sl = s0; sl < s1; ++sl) rad[sl * tm.n_pix_local + pl] = L0;
@@ -1874,8 +1888,9 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 }
             }
             if (!exhausted) {
-                const uint32_t qi = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                if (idle && qi < cur_end) {
+                const uint32_t qi_seq = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && qi_seq < cur_end) {
+                    const uint32_t qi = (!PRIM && tune.perm) ? tune.perm[qi_seq] : qi_seq;  // (sort_rays: a measurement aid)
                     const uint32_t hid = hit[qi];
                     if (hid != HIT_DEAD) {
                         float4 O, D;
@@ -2196,16 +2211,19 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), thr = mk3(0.f, 0.f, 0.f);
     uint32_t id0 = HIT_MISS, rng = 0, depth = 0, pid = 0;
     float d2_0 = 3.402823466e+38f;
+    float4 pre_a = make_float4(0.f, 0.f, 0.f, 0.f), pre_b = pre_a;
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
         const uint32_t id = hit[src];
         if (PRIM) {
             pid = pr.pid[src];
-            uint32_t pixel, sample;
-            primary_ray(pr, pid, o, d, pixel, sample);
+            uint32_t pixel, sample, lp;
+            primary_ray(pr, pid, o, d, pixel, sample, &lp);
             rng = path_seed(pixel, pr.first_sample + sample, pr.seed);
             depth = 0u;
             thr = mk3(1.f, 1.f, 1.f);
+            pre_a = pr.pix[2u * pr.n_pix_local + lp];
+            pre_b = pr.pix[3u * pr.n_pix_local + lp];
         } else {
             const float4 O = ro[src];
             const float4 D = rd[src];
@@ -2218,7 +2236,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
             d = mk3(D.x, D.y, D.z);
         }
         if (id != HIT_DEAD) {
-            const int r = advance_path<1 + FUSE, INST, ABVH, SHADE_BLOCK>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0);
+            const int r = advance_path<1 + FUSE, INST, ABVH, SHADE_BLOCK, PRIM>(sc, id, o, d, thr, rng, depth, max_depth, sp, &rad[pid], id0, d2_0, pre_a, pre_b);
             front = r == 1;
             back = r == 2;
         }
@@ -2232,6 +2250,34 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
         nhit[slot] = id0;
         nhd2[slot] = d2_0;
     }
+}
+
+// Compact primary rays: the surface interaction of a pixel's primary hit, ONCE per pixel.  Without jitter every sample of
+// a pixel traces the same pixel-centre ray (cpu/renderer.cpp:45) -- each of them through the traversal kernel on its own --
+// and finds the same closest hit, so the first k_shade of a batch used to rebuild the same position / normal / material
+// (Triangle::Intersect or the analytic shape again: ~150 wave instructions) once per SAMPLE; a wave there holds 64 samples
+// of one pixel.  This kernel rebuilds it per PIXEL from the hit id of the pixel's first stored sample, and k_shade<PRIM>
+// uses the record for every sample whose own hit id equals the record's (otherwise it computes the hit itself).
+__global__ void __launch_bounds__(256) k_primary_hit(DevScene sc, PrtPrimary pr, const uint32_t* __restrict__ hit,
+                                                     float4* __restrict__ pix) {
+    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+    if (pl >= pr.n_pix_local) return;
+    const float4 E = pix[pr.n_pix_local + pl];
+    float4 a = make_float4(0.f, 0.f, 0.f, __uint_as_float(HIT_DEAD)), b = make_float4(0.f, 0.f, 0.f, 0.f);  // no record
+    if (__float_as_uint(E.w) == 0xFFFFFFFEu) {  // the pixel's paths were stored
+        const uint32_t id = hit[__float_as_uint(E.x)];
+        if (id != HIT_MISS && id != HIT_DEAD) {
+            const float4 P = pix[pl];
+            WorldHit w;
+            world_hit_from_id<false>(sc, id, mk3(pr.origin[0], pr.origin[1], pr.origin[2]), mk3(P.x, P.y, P.z), w);
+            if (w.has) {
+                a = make_float4(w.pos.x, w.pos.y, w.pos.z, __uint_as_float(id));
+                b = make_float4(w.normal.x, w.normal.y, w.normal.z, __uint_as_float(w.material | (w.front ? 0x80000000u : 0u)));
+            }
+        }
+    }
+    pix[2u * pr.n_pix_local + pl] = a;
+    pix[3u * pr.n_pix_local + pl] = b;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2678,6 +2724,10 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
         if (sa) PRT_SHADE(0, true, false, false); else PRT_SHADE(0, false, false, false);
     }
 #undef PRT_SHADE
+}
+
+void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix) {
+    hipLaunchKernelGGL(k_primary_hit, dim3(blocks_for(pr.n_pix_local)), dim3(256), 0, st, sc, pr, hit, pix);
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,

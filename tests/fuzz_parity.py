@@ -89,6 +89,8 @@ def run_case(case, seed):
         params["prim_bvh"] = 0
     if rng.random() < 0.3:
         params["compact_primary"] = 0
+    if rng.random() < 0.2:
+        params["primary_hit"] = 0
     if rng.random() < 0.3:
         params["fuse"] = int(rng.integers(0, 2))
     if rng.random() < 0.2:
@@ -258,7 +260,8 @@ def run_sequence_case(case, seed):
             log.append("sif")
         elif op == "param":
             name, val = [("fuse", int(rng.integers(0, 2))), ("exact_grids", int(rng.integers(0, 3))), ("refill_min", int(rng.choice([1, 16, 64]))),
-                         ("tri_min", int(rng.choice([1, 24, 64]))), ("compact_primary", int(rng.integers(0, 2))), ("steal", int(rng.choice([0, 8])))][int(rng.integers(0, 6))]
+                         ("tri_min", int(rng.choice([1, 24, 64]))), ("compact_primary", int(rng.integers(0, 2))), ("steal", int(rng.choice([0, 8]))),
+                         ("primary_hit", int(rng.integers(0, 2)))][int(rng.integers(0, 7))]
             r.set_param(name, val)
             log.append(f"{name}={val}")
         else:

@@ -326,7 +326,7 @@ def test_image_parity_mesh_scene_vs_linear_scan_oracle():
     assert r.stats().rays_total == rays
 
 
-@pytest.mark.parametrize("fuse", [0, 1, "exact", "exact-fuse", "exact-fullrecords"])
+@pytest.mark.parametrize("fuse", [0, 1, "exact", "exact-fuse", "exact-fullrecords", "exact-nopixelhit"])
 def test_image_parity_bunny_vs_oracle_bvh(fuse):
     """fuse = 1: the producers shade one analytic-only segment in place (paths advance at different rates).
     "exact": k_shade grids sized from the ray counts the host reads back while the traversal runs (the mode big batches
@@ -342,6 +342,8 @@ def test_image_parity_bunny_vs_oracle_bvh(fuse):
         r.set_param("fuse", 1 if fuse.endswith("fuse") else 0)
         if fuse.endswith("fullrecords"):  # k_raygen stores full 56-B ray records instead of compact primary rays
             r.set_param("compact_primary", 0)
+        if fuse.endswith("nopixelhit"):  # the first k_shade rebuilds the primary hit per sample (no k_primary_hit records)
+            r.set_param("primary_hit", 0)
     else:
         r.set_param("fuse", fuse)
     r.ProgressiveRender(spp)
