@@ -194,6 +194,8 @@ typedef struct PrtBvhInfo {
     uint32_t depth8;       /* levels of the 8-wide tree (the traversal stacks at most depth8 - 1 node groups) */
     float build_ms;        /* wall time of the BVH construction (device-side build: without the vertex upload) */
     uint32_t built_on_device; /* 1: built by the device-side builder (prt_set_param("gpu_build", 1)) */
+    float refit_ms;        /* device time of the last prt_refit_meshes (records + boxes bottom-up + re-quantization), 0 = never */
+    uint32_t refits;       /* prt_refit_meshes calls since prt_set_scene */
 } PrtBvhInfo;
 
 /* Static wavefront occupancy of the traversal kernel (the dominant kernel) for the current scene. */
@@ -228,6 +230,14 @@ int prt_set_scene(PrtContext* ctx, const PrtSceneDesc* scene);
 /* Replicates the scene `src` holds (flattened primitives, trees, triangle records) onto dst's device without building
  * anything again: the scene is read-only and every GPU of a multi-GPU render needs its own copy. */
 int prt_clone_scene(PrtContext* dst, const PrtContext* src);
+/* Deforming geometry (SURVEY.md §8f-3 "refit"; the reference rebuilds its OptiX acceleration structures from scratch,
+ * src/backend/optix/renderer.cpp:736-871): the scene's world-space meshes again, with NEW positions / normals and the SAME
+ * vertex counts, triangle counts and index buffers as at prt_set_scene.  The compressed 8-wide tree keeps its topology; its
+ * triangle records are rewritten and its boxes refitted bottom-up and re-quantized on the device.  Scenes with placed
+ * copies (PrtInstance) are not refitted (PRT_ERR_INVALID).  After a refit the A/B kernels over the binary / 4-wide
+ * trees are unavailable (those trees are dropped).  Results equal a fresh prt_set_scene of the new geometry bit for bit
+ * (the closest hit does not depend on the tree); traversal gets slower as the deformation grows. */
+int prt_refit_meshes(PrtContext* ctx, const PrtMesh* meshes, uint32_t n_meshes);
 int prt_set_camera(PrtContext* ctx, const PrtCameraDesc* cam);
 /* Film::Resize + Clear (src/core/film.cu:11-35) and the image partition of this context:
  * 8x8-pixel tiles, tile t (row-major) belongs to rank t % world_size. */

@@ -86,7 +86,7 @@ class PrtBvhInfo(C.Structure):
                 ("max_leaf_size", C.c_uint32), ("sah_cost", C.c_float), ("pad_abs", C.c_float),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("n_nodes4", C.c_uint32), ("max_stack4", C.c_uint32),
                 ("n_nodes8", C.c_uint32), ("depth8", C.c_uint32), ("build_ms", C.c_float),
-                ("built_on_device", C.c_uint32)]
+                ("built_on_device", C.c_uint32), ("refit_ms", C.c_float), ("refits", C.c_uint32)]
 
 
 # numpy dtype mirror of PrtHit (40 bytes)
@@ -149,6 +149,7 @@ SIGNATURES = {
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_kernel_occupancy": (C.c_int, [_vp, C.POINTER(PrtOccupancy)]),
     "prt_kernel_instance": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    "prt_refit_meshes": (C.c_int, [_vp, C.POINTER(PrtMesh), C.c_uint32]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),
     "prt_bvh_read4": (C.c_int, [_vp, _fp]),

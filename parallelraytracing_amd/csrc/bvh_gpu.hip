@@ -210,10 +210,10 @@ __global__ void k_boxes(const float* __restrict__ verts, const uint32_t* __restr
 // Quantization (bvh.h): origin = the node's own minimum, one power-of-two cell per axis, 8-bit planes; the same
 // containment fix-ups as bvh.cpp, in double precision (p + q * cell is exact there).
 __global__ void k_quantize(uint32_t* __restrict__ nodes8, const float* __restrict__ cbox, const float* __restrict__ nbox,
-                           uint32_t n_nodes, uint32_t* __restrict__ counters) {
+                           uint32_t n_nodes, uint32_t* __restrict__ counters, uint32_t stride_dwords = 20u) {
     const uint32_t nd = blockIdx.x * 128u + threadIdx.x;
     if (nd >= n_nodes) return;
-    uint32_t* w = nodes8 + 20 * (size_t)nd;
+    uint32_t* w = nodes8 + (size_t)stride_dwords * nd;
     const float* nb = nbox + 6 * (size_t)nd;
     uint32_t eb[3];
     double cell[3];
@@ -727,7 +727,7 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
         const uint32_t b = level_begin[L], e = level_begin[L + 1];
         hipLaunchKernelGGL(k_boxes, dim3((e - b + 127u) / 128u), dim3(128), 0, st, d_verts, nodes8, order, cbox, nbox, b, e);
     }
-    hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 127u) / 128u), dim3(128), 0, st, nodes8, cbox, nbox, n_nodes, counters);
+    hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 127u) / 128u), dim3(128), 0, st, nodes8, cbox, nbox, n_nodes, counters, 20u);
     hipLaunchKernelGGL(k_records, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, d_norms, d_tri_mat, order, n, n_prims, tris,
                        nrms);
     uint32_t cnt[4];
@@ -1036,6 +1036,121 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
 #undef GB_TRY
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Refit ("SAH refit"): new vertex positions over the EXISTING 8-wide topology (deforming geometry; the
+// reference rebuilds its OptiX structures from scratch, optix/renderer.cpp:736-871).  Three steps, all on the device:
+// the triangle / normal records are rewritten in place in their slot order (a record's w = global primitive index names
+// the input triangle), the children's exact fp32 boxes are recomputed bottom-up, level by level, over the breadth-first
+// node array (the same pass the builder runs, reading the records instead of an order array), and every node is
+// re-quantized by k_quantize with its containment fix-ups.  No sort, no new topology: a refitted tree is as good as the
+// deformation is small (tools/build_compare.py measures the traversal penalty).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_refit_records(const float* __restrict__ verts, const float* __restrict__ norms, uint32_t n, uint32_t n_prims,
+                                float4* __restrict__ tris, float4* __restrict__ nrms) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n) return;
+    const float4 a = tris[3 * (size_t)slot + 0], b = tris[3 * (size_t)slot + 1];
+    const uint32_t t = __float_as_uint(a.w) - n_prims;
+    if (t >= n) return;  // (cannot happen for records the builders wrote)
+    const float* v = verts + 9 * (size_t)t;
+    tris[3 * (size_t)slot + 0] = make_float4(v[0], v[1], v[2], a.w);
+    tris[3 * (size_t)slot + 1] = make_float4(v[3], v[4], v[5], b.w);
+    tris[3 * (size_t)slot + 2] = make_float4(v[6], v[7], v[8], 0.0f);
+    if (norms) {
+        const float* q = norms + 9 * (size_t)t;
+        nrms[3 * (size_t)slot + 0] = make_float4(q[0], q[1], q[2], 0.0f);
+        nrms[3 * (size_t)slot + 1] = make_float4(q[3], q[4], q[5], 0.0f);
+        nrms[3 * (size_t)slot + 2] = make_float4(q[6], q[7], q[8], 0.0f);
+    }
+}
+
+__global__ void k_refit_boxes(const float4* __restrict__ tris, const uint32_t* __restrict__ nodes8, uint32_t stride_dwords,
+                              float* __restrict__ cbox, float* __restrict__ nbox, uint32_t node_begin, uint32_t node_end) {
+    const uint32_t nd = node_begin + blockIdx.x * 128u + threadIdx.x;
+    if (nd >= node_end) return;
+    const uint32_t* w = nodes8 + (size_t)stride_dwords * nd;
+    const uint32_t imask = w[3] >> 24, child_base = w[4], tri_base = w[5];
+    float nmn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float nmx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    uint32_t rank = 0;
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t meta = (w[6 + (c >> 2)] >> (8 * (c & 3))) & 0xFFu;
+        float* cb = cbox + 48 * (size_t)nd + 6 * c;
+        float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+        float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        if (meta) {
+            if ((imask >> c) & 1u) {
+                const float* cbx = nbox + 6 * (size_t)(child_base + rank);
+                ++rank;
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = cbx[a];
+                    mx[a] = cbx[3 + a];
+                }
+            } else {
+                const uint32_t cnt = (uint32_t)__popc(meta >> 5), first = tri_base + (meta & 31u);
+                for (uint32_t k = 0; k < cnt; ++k)
+                    for (int vv = 0; vv < 3; ++vv) {
+                        const float4 v = tris[3 * (size_t)(first + k) + vv];
+                        mn[0] = fminf(mn[0], v.x); mx[0] = fmaxf(mx[0], v.x);
+                        mn[1] = fminf(mn[1], v.y); mx[1] = fmaxf(mx[1], v.y);
+                        mn[2] = fminf(mn[2], v.z); mx[2] = fmaxf(mx[2], v.z);
+                    }
+            }
+            for (int a = 0; a < 3; ++a) {
+                nmn[a] = fminf(nmn[a], mn[a]);
+                nmx[a] = fmaxf(nmx[a], mx[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            cb[a] = mn[a];
+            cb[3 + a] = mx[a];
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        nbox[6 * (size_t)nd + a] = nmn[a];
+        nbox[6 * (size_t)nd + 3 + a] = nmx[a];
+    }
+}
+}  // namespace
+
+int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dwords, uint32_t n_nodes, const uint32_t* level_start,
+                       uint32_t n_levels, const float* d_verts, const float* d_norms, uint32_t n_tris, uint32_t n_prims,
+                       float4* d_tris, float4* d_nrms, float root_box[6]) {
+    if (n_nodes == 0 || n_tris == 0 || n_levels == 0) return 0;
+    float *cbox = nullptr, *nbox = nullptr;
+    uint32_t* counters = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(cbox);
+        (void)hipFree(nbox);
+        (void)hipFree(counters);
+    };
+    hipError_t e = hipMalloc((void**)&cbox, 48 * sizeof(float) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMalloc((void**)&nbox, 6 * sizeof(float) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMalloc((void**)&counters, 4 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+        drop();
+        return (int)e;
+    }
+    hipLaunchKernelGGL(k_refit_records, dim3((n_tris + 255u) / 256u), dim3(256), 0, st, d_verts, d_norms, n_tris, n_prims, d_tris, d_nrms);
+    for (uint32_t l = n_levels; l-- > 0;) {  // deepest level first: a node's internal children are on the next level
+        const uint32_t b = level_start[l], en = level_start[l + 1];
+        if (en > b)
+            hipLaunchKernelGGL(k_refit_boxes, dim3((en - b + 127u) / 128u), dim3(128), 0, st, (const float4*)d_tris, (const uint32_t*)d_nodes8,
+                               stride_dwords, cbox, nbox, b, en);
+    }
+    hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 127u) / 128u), dim3(128), 0, st, d_nodes8, (const float*)cbox, (const float*)nbox, n_nodes,
+                       counters, stride_dwords);
+    uint32_t flags[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(flags, counters, sizeof(flags), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(root_box, nbox, 6 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    drop();
+    if (e != hipSuccess) return (int)e;
+    return flags[2] ? -6 : 0;  // a box that does not fit its node's 8-bit grid (non-finite or absurdly large coordinates)
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Measurement aid, not on the default path (prt_set_param("sort_rays", 1 | 2), tools/sort_ab.py; the round-2 review asked

@@ -54,6 +54,8 @@ struct PrtContext {
     std::vector<float> nrm_records;   // 12 floats per triangle, leaf order
     double gpu_build_ms = 0.0;
     bool scene_device_built = false;  // the scene's 8-wide tree came from the device-side builder (no binary / 4-wide tree)
+    std::vector<uint32_t> mesh_sizes;  // per world-space mesh of the scene: n_vertices, n_triangles (prt_refit_meshes checks them)
+    double refit_ms = 0.0;             // device time of the last prt_refit_meshes (records + boxes + quantization)
     std::vector<uint32_t> nodes8_all;  // scenes with placed mesh copies: top-level tree + every mesh's tree
     std::vector<DevInstance> dev_insts;
     std::vector<uint32_t> tlas_inst;   // top-level leaf slot -> instance
@@ -375,14 +377,13 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
                             c->sort_entries = n_paths;
                         }
                         EventPair es{};
-                        HIPCHECK(c, hipEventSynchronize(ep.a));  // (the traversal's start event is re-recorded after the sort)
                         if ((rc = begin_event(c, 4, &es))) return rc;
                         uint32_t* q = c->d_sort;
                         if (prt_sort_rays(c->stream, in.o, in.d, n_front, c->dsc.root_min, c->dsc.root_max, c->sort_rays, q, q + n_paths,
                                           q + 2 * (size_t)n_paths, q + 3 * (size_t)n_paths, q + 4 * (size_t)n_paths, c->sort_temp))
                             return fail(c, PRT_ERR_HIP, "ray sort failed");
                         if ((rc = end_event(c, &es))) return rc;
-                        if (c->timing) HIPCHECK(c, hipEventRecord(ep.a, c->stream));
+                        if (c->timing) HIPCHECK(c, hipEventRecord(ep.a, c->stream));  // the traversal's own time starts after the sort
                         tune.perm = q + 3 * (size_t)n_paths;
                     }
                 }
@@ -716,6 +717,11 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
             }
         }
     }
+    c->mesh_sizes.clear();
+    for (uint32_t m = 0; m < s->n_meshes; ++m) {
+        c->mesh_sizes.push_back(s->meshes[m].n_vertices);
+        c->mesh_sizes.push_back(s->meshes[m].n_triangles);
+    }
     const uint32_t n_prims = (uint32_t)c->prims.size();
     // device-side build (prt_set_param("gpu_build", 1)): Morton-ordered 8-wide tree straight on the GPU (bvh_gpu.hip);
     // only for world-space meshes on a context with a device; anything else takes the host builder below
@@ -775,6 +781,8 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     bi.depth8 = c->bvh.depth8;
     bi.build_ms = (float)(gpu_build ? c->gpu_build_ms : build_ms);
     bi.built_on_device = (gpu_build || (gpu_any && s->n_instances)) ? 1u : 0u;
+    bi.refit_ms = 0.0f;
+    bi.refits = 0u;
     bi.tri_bytes = (uint64_t)c->tri_records.size() * 4;
 
     DevScene& d = c->dsc;
@@ -1111,11 +1119,119 @@ int prt_clone_scene(PrtContext* dst, const PrtContext* src) {
     dst->bvh_info = src->bvh_info;
     dst->dsc = src->dsc;  // scalar fields; every device pointer is replaced by upload_scene
     dst->scene_device_built = src->scene_device_built;
+    dst->mesh_sizes = src->mesh_sizes;
     if (!dst->has_device) {
         dst->has_scene = true;
         return PRT_OK;
     }
     return upload_scene(dst, nullptr);
+}
+
+// Deforming geometry: the world-space meshes of the current scene with NEW vertex positions / normals (same vertex and
+// triangle counts, same index buffers as at prt_set_scene).  The 8-wide tree keeps its topology and is refitted on the
+// device (csrc/bvh_gpu.hip prt_gpu_bvh8_refit): records rewritten, boxes recomputed bottom-up, nodes re-quantized.
+int prt_refit_meshes(PrtContext* c, const PrtMesh* meshes, uint32_t n_meshes) {
+    int rc = need_device(c);
+    if (rc) return rc;
+    if (!c->has_scene) return fail(c, PRT_ERR_INVALID, "prt_set_scene has not been called");
+    if (!meshes && n_meshes) return fail(c, PRT_ERR_INVALID, "null mesh array");
+    if (c->dsc.n_insts) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: scenes with placed copies are rebuilt, not refitted");
+    if (!c->dsc.nodes8 || c->bvh.nodes8.empty()) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes needs the compressed 8-wide tree");
+    if (2 * (size_t)n_meshes != c->mesh_sizes.size()) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: the scene has %zu meshes", c->mesh_sizes.size() / 2);
+    uint64_t n_tris = 0;
+    for (uint32_t m = 0; m < n_meshes; ++m) {
+        const PrtMesh& me = meshes[m];
+        if (me.n_vertices != c->mesh_sizes[2 * m] || me.n_triangles != c->mesh_sizes[2 * m + 1])
+            return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: mesh %u has another topology than at prt_set_scene", m);
+        if (me.n_triangles && (!me.positions || !me.normals || !me.indices)) return fail(c, PRT_ERR_INVALID, "mesh %u: positions, normals and indices are required", m);
+        n_tris += me.n_triangles;
+    }
+    if (n_tris != c->dsc.n_tris || n_tris == 0) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: triangle count mismatch");
+    std::vector<float> verts(9 * (size_t)n_tris), norms(9 * (size_t)n_tris);
+    float extent = 0.0f;
+    {
+        size_t t = 0;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const PrtMesh& me = meshes[m];
+            for (uint32_t k = 0; k < me.n_triangles; ++k, ++t)
+                for (int v = 0; v < 3; ++v) {
+                    const uint32_t vi = me.indices[3 * (size_t)k + v];
+                    if (vi >= me.n_vertices) return fail(c, PRT_ERR_INVALID, "mesh %u: vertex index out of range", m);
+                    for (int a = 0; a < 3; ++a) {
+                        const float pv = me.positions[3 * (size_t)vi + a];
+                        if (!std::isfinite(pv)) return fail(c, PRT_ERR_INVALID, "mesh %u: non-finite vertex", m);
+                        verts[9 * t + 3 * v + a] = pv;
+                        norms[9 * t + 3 * v + a] = me.normals[3 * (size_t)vi + a];
+                        extent = std::max(extent, std::fabs(pv));
+                    }
+                }
+        }
+    }
+    // levels of the breadth-first node array, from the host copy of the tree: the internal children of level l's nodes
+    // are exactly level l + 1, in order
+    const std::vector<uint32_t>& n8 = c->bvh.nodes8;
+    const uint32_t n_nodes = (uint32_t)(n8.size() / 20);
+    std::vector<uint32_t> level_start{0u, 1u};
+    for (;;) {
+        const uint32_t b = level_start[level_start.size() - 2], e = level_start.back();
+        uint64_t kids = 0;
+        bool ordered = true;
+        for (uint32_t nd = b; nd < e; ++nd) {
+            const uint32_t imask = n8[20 * (size_t)nd + 3] >> 24;
+            if (imask && n8[20 * (size_t)nd + 4] != e + kids) ordered = false;
+            kids += (uint32_t)__builtin_popcount(imask);
+        }
+        if (!ordered || e + kids > n_nodes) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: the tree's node array is not breadth first");
+        if (kids == 0) break;
+        level_start.push_back((uint32_t)(e + kids));
+    }
+    if (level_start.back() != n_nodes) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: the tree's node array is not breadth first");
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    void *dv = nullptr, *dn = nullptr;
+    hipError_t e = hipMalloc(&dv, 36 * (size_t)n_tris);
+    if (e == hipSuccess) e = hipMalloc(&dn, 36 * (size_t)n_tris);
+    if (e == hipSuccess) e = hipMemcpy(dv, verts.data(), 36 * (size_t)n_tris, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dn, norms.data(), 36 * (size_t)n_tris, hipMemcpyHostToDevice);
+    float root_box[6] = {0, 0, 0, 0, 0, 0};
+    int brc = 0;
+    if (e == hipSuccess) {
+        const auto t0 = std::chrono::steady_clock::now();
+        brc = prt_gpu_bvh8_refit(c->stream, (uint32_t*)c->d_nodes8, c->dsc.node_stride * 4u, n_nodes, level_start.data(),
+                                 (uint32_t)level_start.size() - 1u, (const float*)dv, (const float*)dn, (uint32_t)n_tris, c->dsc.n_prims,
+                                 (float4*)c->d_tris, (float4*)c->d_nrms, root_box);
+        c->refit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    (void)hipFree(dv);
+    (void)hipFree(dn);
+    if (e != hipSuccess || brc) {
+        c->has_scene = false;  // the device arrays may be half rewritten
+        return fail(c, PRT_ERR_HIP, "prt_refit_meshes: %s (%d)", e != hipSuccess ? hipGetErrorString(e) : "refit failed", brc);
+    }
+    // host copies (prt_bvh_read8 / prt_bvh_read, prt_clone_scene) follow the device
+    e = hipMemcpy2D(c->bvh.nodes8.data(), 80, c->d_nodes8, (size_t)c->dsc.node_stride * 16, 80, n_nodes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && c->tri_records.size() == 12 * (size_t)n_tris) e = hipMemcpy(c->tri_records.data(), c->d_tris, 48 * (size_t)n_tris, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && c->nrm_records.size() == 12 * (size_t)n_tris) e = hipMemcpy(c->nrm_records.data(), c->d_nrms, 48 * (size_t)n_tris, hipMemcpyDeviceToHost);
+    HIPCHECK(c, e);
+    // the binary and 4-wide trees (A/B kernels, overflow fallback of deep host-built trees) still describe the OLD
+    // geometry: they go, and the instance selection falls to the 8-wide kernels that need neither (prt_launch_traverse)
+    free_dev(c->d_nodes);
+    free_dev(c->d_nodes4);
+    c->dsc.nodes = nullptr;
+    c->dsc.nodes4 = nullptr;
+    c->bvh.nodes.clear();
+    c->bvh.nodes4.clear();
+    c->scene_device_built = true;
+    c->variant = 0;
+    for (int a = 0; a < 3; ++a) {
+        c->dsc.root_min[a] = root_box[a];
+        c->dsc.root_max[a] = root_box[3 + a];
+    }
+    float ext_all = extent;
+    if (!c->abvh.nodes4.empty()) ext_all = std::max(ext_all, c->dsc.extent);  // (the primitive walk's pad scales with the larger of the two)
+    c->dsc.extent = ext_all;
+    c->bvh_info.refit_ms = (float)c->refit_ms;
+    ++c->bvh_info.refits;
+    return PRT_OK;
 }
 
 int prt_set_camera(PrtContext* c, const PrtCameraDesc* cam) {

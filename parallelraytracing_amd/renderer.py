@@ -453,6 +453,14 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_kernel_occupancy(self._ctx, C.byref(o)))
         return o
 
+    def Refit(self, scene: "Scene"):
+        """prt_refit_meshes: `scene`'s world-space meshes carry new vertex positions / normals over the topology the
+        renderer was initialised with; the 8-wide tree is refitted on the device (no rebuild)."""
+        d = scene.desc()
+        scene._keep = d
+        self._check(capi.lib().prt_refit_meshes(self._ctx, d.meshes, d.n_meshes))
+        self._scene = scene
+
     def kernel_instance(self) -> str:
         """Name of the traversal kernel instance the scene and tunables select (prt_kernel_instance)."""
         buf = C.create_string_buffer(64)

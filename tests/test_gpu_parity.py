@@ -819,3 +819,72 @@ def test_full_size_properties(W, H):
                                                   n_threads=8, rect=rect)
     x0, y0, x1, y1 = rect
     assert np.array_equal(acc[y0:y1, x0:x1], a[y0:y1, x0:x1])
+
+
+# ---- refit (prt_refit_meshes: new vertex positions over the existing 8-wide topology, on the device) --------------------
+def _deformed(mesh, amp, seed):
+    """The same topology with every vertex moved: a smooth bend plus per-vertex noise of `amp`."""
+    v = mesh.GetVertices().astype(np.float64)
+    rng = np.random.default_rng(seed)
+    v[:, 0] += amp * 4.0 * np.sin(3.0 * v[:, 1])
+    v[:, 2] += amp * 4.0 * np.cos(2.0 * v[:, 0])
+    v += rng.normal(size=v.shape) * amp
+    n = mesh.GetNormals()
+    return prt.Mesh(vertices=v.astype(np.float32), normals=n, indices=mesh.GetIndices())
+
+
+@pytest.mark.parametrize("builder,target", [(0, 6_000), (1, 30_000), (0, 120_000)])
+def test_refitted_tree_is_valid_and_renders_the_deformed_mesh_bit_exact(builder, target):
+    """The tree built for the ORIGINAL mesh, refitted on the device to a deformed copy: structurally valid (every quantized
+    box contains what is below it), closest hits and image bit-exact against the oracle on the deformed mesh (the oracle
+    scans / builds its own tree from the new geometry), and equal to a fresh build of the deformed scene."""
+    base = prt.scenes.refined("bunny.ply", target)
+    moved = _deformed(base, 0.01, 5)
+    W, H, spp, depth = 96, 54, 2, 5
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=3)
+    r.set_param("gpu_build", builder)
+    film = prt.Film(W, H)
+    r.Init(film, prt.scenes.mesh_scene(base), cam)
+    r.ProgressiveRender(1)  # (the renderer has worked with the old geometry)
+    scene2 = prt.scenes.mesh_scene(moved)
+    r.Refit(scene2)
+    n8 = r.bvh_read8()
+    _, tris = r.bvh_read()
+    fill, levels = util.check_bvh8(n8, tris)
+    assert levels == r.bvh_info().depth8
+    prim = tris[:, 3].view(np.uint32).astype(np.int64) - len(scene2.primitives)
+    assert sorted(prim.tolist()) == list(range(moved.n_triangles))
+    osc = util.oracle_scene(scene2)
+    o, d = _mesh_rays(np.random.default_rng(7), 5000)
+    got = r.closest_hit(o, d)
+    want = osc.closest_hit(o, d, use_bvh=target > 10_000, n_threads=8)
+    assert util.hits_equal(got, want) == []
+    assert (got["prim"] >= 2).sum() > 300
+    film.Clear()
+    r.frame_index = 0
+    r.reset_stats()
+    r.ProgressiveRender(spp)
+    r.download()
+    acc, wts, rays = osc.render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=3, iterative=True, use_bvh=True, n_threads=8)
+    assert np.array_equal(film.accum, acc) and r.stats().rays_total == rays
+    # a fresh build of the deformed scene gives the same frame
+    r2 = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=3)
+    film2 = prt.Film(W, H)
+    r2.Init(film2, scene2, cam)
+    r2.ProgressiveRender(spp)
+    r2.download()
+    assert np.array_equal(film2.accum, film.accum)
+
+
+def test_refit_rejects_another_topology_and_placed_copies():
+    base = prt.scenes.refined("bunny.ply", 6_000)
+    r = prt.HipWavefrontRenderer(device=0)
+    film = prt.Film(16, 16)
+    r.Init(film, prt.scenes.mesh_scene(base), prt.Camera(width=16, height=16))
+    other = prt.scenes.refined("bunny.ply", 6_100)
+    with pytest.raises(prt.PrtError):
+        r.Refit(prt.scenes.mesh_scene(other))
+    # the scene the renderer holds is untouched by the refused call
+    o, d = _mesh_rays(np.random.default_rng(3), 500)
+    assert util.hits_equal(r.closest_hit(o, d), util.oracle_scene(prt.scenes.mesh_scene(base)).closest_hit(o, d, use_bvh=False, n_threads=8)) == []

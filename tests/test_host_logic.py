@@ -31,6 +31,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.PrtMaterial) == 20 and C.sizeof(capi.PrtPrimitive) == 144
     assert C.sizeof(capi.PrtHit) == 40 and np.dtype(capi.HIT_DTYPE).itemsize == 40
     assert C.sizeof(capi.PrtCameraDesc) == 32
+    assert C.sizeof(capi.PrtBvhInfo) == 72
     assert C.sizeof(capi.PrtStats) == 8 * (1 + 64 + 2) + 8 * 4 + 8 * 3 + 16 + 8 + 8 + 8 + 24
 
 
