@@ -212,7 +212,10 @@ typedef struct PrtOccupancy {
 typedef struct PrtContext PrtContext;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
-/* device_id < 0: host-only context (scene/mesh/BVH utilities work, compute calls fail loudly). */
+/* device_id < 0: host-only context (scene/mesh/BVH utilities work, compute calls fail loudly).
+ * Side effect of every call that touches the device: it makes the context's GPU the CALLING THREAD's current HIP device
+ * (hipSetDevice) and leaves it so; a host that holds several devices (a torch process, say) restores its own afterwards
+ * or calls from a thread of its own, as prt_group_* does. */
 int prt_create(int device_id, PrtContext** out);
 void prt_destroy(PrtContext* ctx);
 const char* prt_last_error(const PrtContext* ctx);
@@ -334,7 +337,10 @@ int prt_set_param(PrtContext* ctx, const char* name, int value);
  *   transport "peer": hipMemcpyPeerAsync into rank 0's buffer (also the fallback, and what several ranks on ONE device use)
  * PRT_GROUP_TRANSPORT=rccl|peer overrides the choice (rccl with a single rank runs a 1-rank ncclAllGather: a hardware
  * smoke test of the RCCL path).  The same device may appear several times in device_ids (rehearsal / tests on one GPU).
- * All calls are synchronous and are made from one caller thread. */
+ * All calls are synchronous and are made from one caller thread.
+ * prt_group_create ALWAYS stores a group in *out, also when it returns an error (so that prt_group_last_error can say why):
+ * the caller destroys it with prt_group_destroy in either case.  The "rccl" transport with n > 1 distinct devices has not
+ * run on hardware yet (no multi-GPU box was available to the builder; prt_group_transport says which one a group uses). */
 typedef struct PrtGroup PrtGroup;
 int prt_group_create(const int* device_ids, uint32_t n, PrtGroup** out);
 void prt_group_destroy(PrtGroup* g);

@@ -20,7 +20,7 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
 // topology and the SAH-optimal collapse to 8-wide nodes by dynamic programming, all on the device.  Same contract.
 // leaf_cost: cost of testing one primitive of a leaf relative to one 8-wide node visit (0 = the builder's default for
 // triangles; large for a top-level tree, whose "primitives" are whole instances that are entered without a box test of
-// their own: every instance then gets a leaf to itself).
+// their own: every instance then gets a leaf to itself, except copies whose boxes coincide).
 int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d_norms, const uint32_t* d_tri_mat, uint32_t n_tris,
                             uint32_t n_prims, const float cmin[3], const float cmax[3], PrtGpuBvh* out, float leaf_cost = 0.0f);
 
@@ -32,10 +32,11 @@ int prt_sort_rays(hipStream_t st, const float4* ro, const float4* rd, uint32_t n
                   uint32_t mode, uint32_t* keys, uint32_t* keys2, uint32_t* idx, uint32_t* idx2, void* temp, size_t temp_bytes);
 
 // Refit: new vertex positions over an existing 8-wide tree on the device.  d_nodes8: n_nodes nodes at a stride of
-// stride_dwords (20 packed / 32 one node per 128-B line), breadth first, level l = nodes [level_start[l], level_start[l + 1])
-// (host array of n_levels + 1 entries); d_verts / d_norms: 9 floats per triangle in INPUT order (d_norms may be null);
+// stride_dwords (20 packed / 32 one node per 128-B line); level_nodes (HOST array, n_nodes entries): the node indices sorted
+// by tree level, level l = level_nodes[level_start[l] .. level_start[l + 1]) (level_start: host array of n_levels + 1
+// entries); d_verts / d_norms: 9 floats per triangle in INPUT order (d_norms may be null);
 // d_tris / d_nrms: the scene's records in slot order, rewritten in place.  root_box[6] receives the new root bounds.
 // Synchronous.  Returns 0, a hipError_t, or -6 if a box does not fit its node's quantization grid.
-int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dwords, uint32_t n_nodes, const uint32_t* level_start,
-                       uint32_t n_levels, const float* d_verts, const float* d_norms, uint32_t n_tris, uint32_t n_prims,
-                       float4* d_tris, float4* d_nrms, float root_box[6]);
+int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dwords, uint32_t n_nodes, const uint32_t* level_nodes,
+                       const uint32_t* level_start, uint32_t n_levels, const float* d_verts, const float* d_norms, uint32_t n_tris,
+                       uint32_t n_prims, float4* d_tris, float4* d_nrms, float root_box[6]);

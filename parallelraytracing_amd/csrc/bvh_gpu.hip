@@ -326,8 +326,12 @@ __global__ void k_ploc_leaves(const float* __restrict__ verts, const uint32_t* _
     cl[i] = i;
 }
 
-// nearest neighbour of every cluster within PLOC_RADIUS positions (merged-box area; ties to the lower position, which
-// makes "mutual" well defined: the globally best pair is always mutual, so every pass merges at least one pair)
+// nearest neighbour of every cluster within PLOC_RADIUS positions.  Candidates are ranked by a key that is SYMMETRIC in the
+// pair: (merged-box area, distance in the array, parity of the lower position, lower position), so the globally best pair is
+// the best pair of both its members: it is mutual and every pass merges at least one pair.  The tie terms matter for runs
+// of clusters with identical boxes (coincident or duplicated triangles): "lowest position wins" made all of them point at
+// the run's first cluster, one merge per pass and a pass per triangle; nearest-then-even-lower-position pairs the run up
+// as (0,1), (2,3), ... and halves it per pass.
 __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ box,
                                                  uint32_t* __restrict__ nn, int PLOC_RADIUS) {
     __shared__ float s_box[(256 + 2 * PLOC_RADIUS_MAX) * 6];
@@ -344,6 +348,7 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ cl
     if (i >= m) return;
     const float* bi = &s_box[6 * ((int)threadIdx.x + PLOC_RADIUS)];
     float best = 3.402823466e+38f;
+    unsigned long long best_tie = ~0ull;
     uint32_t bj = i;
     const int j0 = (int)i - PLOC_RADIUS < 0 ? 0 : (int)i - PLOC_RADIUS;
     const int j1 = (int)i + PLOC_RADIUS >= (int)m ? (int)m - 1 : (int)i + PLOC_RADIUS;
@@ -356,8 +361,11 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ cl
             hi[a] = fmaxf(bi[3 + a], bq[3 + a]);
         }
         const float ar = half_area6(lo, hi);
-        if (ar < best) {  // strict: ties keep the lower position
+        const uint32_t lowp = (uint32_t)j < i ? (uint32_t)j : i, dist = (uint32_t)j < i ? i - (uint32_t)j : (uint32_t)j - i;
+        const unsigned long long tie = ((unsigned long long)dist << 33) | ((unsigned long long)(lowp & 1u) << 32) | lowp;
+        if (ar < best || (ar == best && tie < best_tie)) {
             best = ar;
+            best_tie = tie;
             bj = (uint32_t)j;
         }
     }
@@ -1041,8 +1049,9 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
 // Refit ("SAH refit"): new vertex positions over the EXISTING 8-wide topology (deforming geometry; the
 // reference rebuilds its OptiX structures from scratch, optix/renderer.cpp:736-871).  Three steps, all on the device:
 // the triangle / normal records are rewritten in place in their slot order (a record's w = global primitive index names
-// the input triangle), the children's exact fp32 boxes are recomputed bottom-up, level by level, over the breadth-first
-// node array (the same pass the builder runs, reading the records instead of an order array), and every node is
+// the input triangle), the children's exact fp32 boxes are recomputed bottom-up, level by level (the host hands over
+// the nodes of every level as a list: the builders' node orders differ; the same pass the builder runs, reading the
+// records instead of an order array), and every node is
 // re-quantized by k_quantize with its containment fix-ups.  No sort, no new topology: a refitted tree is as good as the
 // deformation is small (tools/build_compare.py measures the traversal penalty).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1067,9 +1076,11 @@ __global__ void k_refit_records(const float* __restrict__ verts, const float* __
 }
 
 __global__ void k_refit_boxes(const float4* __restrict__ tris, const uint32_t* __restrict__ nodes8, uint32_t stride_dwords,
-                              float* __restrict__ cbox, float* __restrict__ nbox, uint32_t node_begin, uint32_t node_end) {
-    const uint32_t nd = node_begin + blockIdx.x * 128u + threadIdx.x;
-    if (nd >= node_end) return;
+                              float* __restrict__ cbox, float* __restrict__ nbox, const uint32_t* __restrict__ level_nodes,
+                              uint32_t list_begin, uint32_t list_end) {
+    const uint32_t li = list_begin + blockIdx.x * 128u + threadIdx.x;
+    if (li >= list_end) return;
+    const uint32_t nd = level_nodes[li];
     const uint32_t* w = nodes8 + (size_t)stride_dwords * nd;
     const uint32_t imask = w[3] >> 24, child_base = w[4], tri_base = w[5];
     float nmn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
@@ -1115,20 +1126,23 @@ __global__ void k_refit_boxes(const float4* __restrict__ tris, const uint32_t* _
 }
 }  // namespace
 
-int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dwords, uint32_t n_nodes, const uint32_t* level_start,
-                       uint32_t n_levels, const float* d_verts, const float* d_norms, uint32_t n_tris, uint32_t n_prims,
-                       float4* d_tris, float4* d_nrms, float root_box[6]) {
+int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dwords, uint32_t n_nodes, const uint32_t* level_nodes,
+                       const uint32_t* level_start, uint32_t n_levels, const float* d_verts, const float* d_norms, uint32_t n_tris,
+                       uint32_t n_prims, float4* d_tris, float4* d_nrms, float root_box[6]) {
     if (n_nodes == 0 || n_tris == 0 || n_levels == 0) return 0;
     float *cbox = nullptr, *nbox = nullptr;
-    uint32_t* counters = nullptr;
+    uint32_t *counters = nullptr, *d_list = nullptr;
     auto drop = [&]() {
         (void)hipFree(cbox);
         (void)hipFree(nbox);
         (void)hipFree(counters);
+        (void)hipFree(d_list);
     };
     hipError_t e = hipMalloc((void**)&cbox, 48 * sizeof(float) * (size_t)n_nodes);
     if (e == hipSuccess) e = hipMalloc((void**)&nbox, 6 * sizeof(float) * (size_t)n_nodes);
     if (e == hipSuccess) e = hipMalloc((void**)&counters, 4 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_list, sizeof(uint32_t) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_list, level_nodes, sizeof(uint32_t) * (size_t)n_nodes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), st);
     if (e != hipSuccess) {
         drop();
@@ -1139,7 +1153,7 @@ int prt_gpu_bvh8_refit(hipStream_t st, uint32_t* d_nodes8, uint32_t stride_dword
         const uint32_t b = level_start[l], en = level_start[l + 1];
         if (en > b)
             hipLaunchKernelGGL(k_refit_boxes, dim3((en - b + 127u) / 128u), dim3(128), 0, st, (const float4*)d_tris, (const uint32_t*)d_nodes8,
-                               stride_dwords, cbox, nbox, b, en);
+                               stride_dwords, cbox, nbox, (const uint32_t*)d_list, b, en);
     }
     hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 127u) / 128u), dim3(128), 0, st, d_nodes8, (const float*)cbox, (const float*)nbox, n_nodes,
                        counters, stride_dwords);

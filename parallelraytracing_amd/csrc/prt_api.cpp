@@ -453,6 +453,7 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
         if (e == hipSuccess)
             e = gb ? hipMemcpy2D(wide, 128, c->d_nodes8, 80, 80, n_nodes8, hipMemcpyDeviceToDevice)
                    : hipMemcpy2D(wide, 128, n8.data(), 80, 80, n_nodes8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // (device-to-device copies on the null stream return early; renders use c->stream)
         if (e != hipSuccess) {
             (void)hipFree(wide);
             HIPCHECK(c, e);
@@ -518,6 +519,7 @@ int upload_scene(PrtContext* c, PrtGpuBvh* gb) {
 // Device-side build (csrc/bvh_gpu.hip) of the 8-wide tree over n triangles given as 9 floats each (+ normals, + a material
 // per triangle): nodes and the triangle / normal records in the tree's slot order come back to the host copies the
 // rest of prt_set_scene works with; with `keep` the device arrays stay allocated and are handed to the caller.
+constexpr int kDeviceBuildGaveUp = -1000;  // internal: not a PRT_ERR_* code
 int device_build(PrtContext* c, const float* verts, const float* norms, const uint32_t* tri_mat, uint32_t n, uint32_t n_prims,
                  std::vector<uint32_t>& nodes8, uint32_t& depth, float* tri_rec, float* nrm_rec, PrtGpuBvh* keep, float leaf_cost = 0.0f) {
     float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -541,8 +543,9 @@ int device_build(PrtContext* c, const float* verts, const float* norms, const ui
     if (e == hipSuccess) e = hipMalloc(&dn, 36 * (size_t)n);
     if (e == hipSuccess) e = hipMalloc(&dm, 4 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpy(dv, verts, 36 * (size_t)n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = norms ? hipMemcpy(dn, norms, 36 * (size_t)n, hipMemcpyHostToDevice) : hipMemset(dn, 0, 36 * (size_t)n);
-    if (e == hipSuccess) e = tri_mat ? hipMemcpy(dm, tri_mat, 4 * (size_t)n, hipMemcpyHostToDevice) : hipMemset(dm, 0, 4 * (size_t)n);
+    // (fills on the stream the builder's kernels run on: c->stream is non-blocking, nothing orders it after the null stream)
+    if (e == hipSuccess) e = norms ? hipMemcpy(dn, norms, 36 * (size_t)n, hipMemcpyHostToDevice) : hipMemsetAsync(dn, 0, 36 * (size_t)n, c->stream);
+    if (e == hipSuccess) e = tri_mat ? hipMemcpy(dm, tri_mat, 4 * (size_t)n, hipMemcpyHostToDevice) : hipMemsetAsync(dm, 0, 4 * (size_t)n, c->stream);
     if (e != hipSuccess) {
         drop();
         return fail(c, PRT_ERR_HIP, "device-side BVH build: %s", hipGetErrorString(e));
@@ -555,6 +558,10 @@ int device_build(PrtContext* c, const float* verts, const float* norms, const ui
                         : prt_gpu_bvh8_build_ploc(c->stream, (const float*)dv, (const float*)dn, (const uint32_t*)dm, n, n_prims, cmin, cmax, &gb, leaf_cost);
     c->gpu_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     drop();
+    if (brc < 0) {  // the builder itself gave up (too many passes / levels for this input): the caller may take the host builder
+        (void)fail(c, PRT_ERR_INVALID, "device-side BVH build gave up (%d)", brc);
+        return kDeviceBuildGaveUp;
+    }
     if (brc) return fail(c, PRT_ERR_HIP, "device-side BVH build failed (%d)", brc);
     nodes8.resize(20 * (size_t)gb.n_nodes);
     depth = gb.depth;
@@ -726,7 +733,7 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
     // device-side build (prt_set_param("gpu_build", 1)): Morton-ordered 8-wide tree straight on the GPU (bvh_gpu.hip);
     // only for world-space meshes on a context with a device; anything else takes the host builder below
     const bool gpu_any = c->gpu_build && c->has_device;  // placed copies and the top-level tree take the device builder too
-    const bool gpu_build = gpu_any && n_tris > 0;
+    bool gpu_build = gpu_any && n_tris > 0;
     PrtGpuBvh gb{};
     c->gpu_build_ms = 0.0;
     const auto t_build0 = std::chrono::steady_clock::now();
@@ -739,14 +746,22 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         c->nrm_records.assign(12 * (size_t)n_tris, 0.0f);
         const int brc = device_build(c, verts.data(), norms.data(), tri_mat.data(), (uint32_t)n_tris, n_prims, c->bvh.nodes8, c->bvh.depth8,
                                      c->tri_records.data(), c->nrm_records.data(), s->n_instances == 0 ? &gb : nullptr);
-        if (brc) return brc;
-        if (c->bvh.depth8 > 15u) {
+        if (brc && brc != kDeviceBuildGaveUp) return brc;
+        if (!brc && c->bvh.depth8 > 15u) {
             (void)hipFree(gb.d_nodes8);
             (void)hipFree(gb.d_tris);
             (void)hipFree(gb.d_nrms);
-            return fail(c, PRT_ERR_INVALID, "device-built BVH too deep for the traversal stack (%u > 15)", c->bvh.depth8);
         }
-    } else if (!bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh)) {
+        // A valid mesh is never refused because the DEVICE builder could not cope with it (a tree deeper than the kernels'
+        // stacks, or more clustering passes than its guard allows: degenerate inputs such as thousands of coincident
+        // triangles): the host builder, with its forced median splits, takes over.
+        if (brc == kDeviceBuildGaveUp || c->bvh.depth8 > 15u) {
+            gb = PrtGpuBvh{};
+            gpu_build = false;
+            c->bvh = BvhBuild();
+        }
+    }
+    if (!gpu_build && !bvh_build(verts.data(), (uint32_t)n_tris, kMaxLeaf, 0, kMaxStack, &c->bvh)) {
         return fail(c, PRT_ERR_INVALID, "BVH deeper than the traversal stack (%u > %u)", c->bvh.max_depth, kMaxStack);
     }
     const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
@@ -920,8 +935,9 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
             if (gpu_any) {  // the mesh's tree in its own space on the device; the records come back in its slot order
                 const int brc = device_build(c, v.data(), nn.data(), nullptr, me.n_triangles, 0u, B.bvh.nodes8, B.bvh.depth8,
                                              &c->tri_records[12 * (size_t)B.slot_base], &c->nrm_records[12 * (size_t)B.slot_base], nullptr);
-                if (brc) return brc;
-                continue;
+                if (brc && brc != kDeviceBuildGaveUp) return brc;
+                if (!brc) continue;
+                B.bvh = BvhBuild();  // the device builder gave up on this mesh: the host builder takes it
             }
             if (!bvh_build(v.data(), me.n_triangles, kMaxLeaf, 0, kMaxStack, &B.bvh) || B.bvh.nodes8.empty())
                 return fail(c, PRT_ERR_INVALID, "instanced mesh %u: BVH construction failed", m);
@@ -1031,8 +1047,10 @@ int prt_set_scene(PrtContext* c, const PrtSceneDesc* s) {
         if (gpu_any) {  // the same device builder over the copies' boxes; a record's primitive index is the instance it stands for
             std::vector<float> rec(12 * (size_t)n_inst_total);
             // (an instance in a hit leaf is ENTERED, a level switch of ~150 instructions, without a box test of its own:
-            // a leaf cost this high gives every instance a leaf to itself)
+            // a leaf cost this high makes the optimisation put every instance into a leaf of its own wherever the boxes
+            // differ; copies whose boxes coincide may still share a leaf, which costs a redundant entry, never a result)
             const int brc = device_build(c, pv.data(), nullptr, nullptr, n_inst_total, 0u, top.nodes8, top.depth8, rec.data(), nullptr, nullptr, 64.0f);
+            if (brc == kDeviceBuildGaveUp) return fail(c, PRT_ERR_INVALID, "top-level tree: the device builder gave up; use gpu_build = 0 for this scene");
             if (brc) return brc;
             top.order.resize(n_inst_total);
             for (uint32_t sl = 0; sl < n_inst_total; ++sl) memcpy(&top.order[sl], &rec[12 * (size_t)sl + 3], 4);
@@ -1167,25 +1185,26 @@ int prt_refit_meshes(PrtContext* c, const PrtMesh* meshes, uint32_t n_meshes) {
                 }
         }
     }
-    // levels of the breadth-first node array, from the host copy of the tree: the internal children of level l's nodes
-    // are exactly level l + 1, in order
+    // the nodes of every tree level, from the host copy of the tree (breadth-first search from the root: the builders emit
+    // their nodes in different orders, none of which the refit relies on)
     const std::vector<uint32_t>& n8 = c->bvh.nodes8;
     const uint32_t n_nodes = (uint32_t)(n8.size() / 20);
-    std::vector<uint32_t> level_start{0u, 1u};
+    std::vector<uint32_t> level_nodes{0u}, level_start{0u, 1u};
+    level_nodes.reserve(n_nodes);
     for (;;) {
         const uint32_t b = level_start[level_start.size() - 2], e = level_start.back();
-        uint64_t kids = 0;
-        bool ordered = true;
-        for (uint32_t nd = b; nd < e; ++nd) {
-            const uint32_t imask = n8[20 * (size_t)nd + 3] >> 24;
-            if (imask && n8[20 * (size_t)nd + 4] != e + kids) ordered = false;
-            kids += (uint32_t)__builtin_popcount(imask);
+        for (uint32_t li = b; li < e; ++li) {
+            const uint32_t nd = level_nodes[li];
+            const uint32_t imask = n8[20 * (size_t)nd + 3] >> 24, child_base = n8[20 * (size_t)nd + 4];
+            const uint32_t kids = (uint32_t)__builtin_popcount(imask);
+            if ((uint64_t)child_base + kids > n_nodes || level_nodes.size() + kids > n_nodes)
+                return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: malformed tree (node %u)", nd);
+            for (uint32_t k = 0; k < kids; ++k) level_nodes.push_back(child_base + k);
         }
-        if (!ordered || e + kids > n_nodes) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: the tree's node array is not breadth first");
-        if (kids == 0) break;
-        level_start.push_back((uint32_t)(e + kids));
+        if (level_nodes.size() == e) break;
+        level_start.push_back((uint32_t)level_nodes.size());
     }
-    if (level_start.back() != n_nodes) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: the tree's node array is not breadth first");
+    if (level_nodes.size() != n_nodes) return fail(c, PRT_ERR_INVALID, "prt_refit_meshes: %zu of %u nodes reachable from the root", level_nodes.size(), n_nodes);
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     void *dv = nullptr, *dn = nullptr;
     hipError_t e = hipMalloc(&dv, 36 * (size_t)n_tris);
@@ -1196,7 +1215,7 @@ int prt_refit_meshes(PrtContext* c, const PrtMesh* meshes, uint32_t n_meshes) {
     int brc = 0;
     if (e == hipSuccess) {
         const auto t0 = std::chrono::steady_clock::now();
-        brc = prt_gpu_bvh8_refit(c->stream, (uint32_t*)c->d_nodes8, c->dsc.node_stride * 4u, n_nodes, level_start.data(),
+        brc = prt_gpu_bvh8_refit(c->stream, (uint32_t*)c->d_nodes8, c->dsc.node_stride * 4u, n_nodes, level_nodes.data(), level_start.data(),
                                  (uint32_t)level_start.size() - 1u, (const float*)dv, (const float*)dn, (uint32_t)n_tris, c->dsc.n_prims,
                                  (float4*)c->d_tris, (float4*)c->d_nrms, root_box);
         c->refit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

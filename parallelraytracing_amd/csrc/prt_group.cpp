@@ -91,17 +91,26 @@ int gfail(PrtGroup* g, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return gfail((g), PRT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// f(rank) on one host thread per rank; the first non-zero status (with that context's message) wins.
-int for_each_rank(PrtGroup* g, const std::function<int(uint32_t)>& f) {
+// f(rank) for every rank; the first non-zero status (with that context's message) wins.  threads = true: one host thread
+// per rank (renders, uploads: each call drives its GPU for a while); false: in turn on the caller's thread (setters that
+// only store a value: a thread each would cost more than the call).  No exception leaves this function: a thread that
+// cannot be started (std::system_error) turns into PRT_ERR_HIP after the threads that did start have been joined.
+int for_each_rank(PrtGroup* g, const std::function<int(uint32_t)>& f, bool threads = true) {
     const uint32_t n = (uint32_t)g->ctx.size();
     std::vector<int> rc(n, 0);
-    if (n == 1) {
-        rc[0] = f(0);
+    if (n == 1 || !threads) {
+        for (uint32_t r = 0; r < n; ++r) rc[r] = f(r);
     } else {
         std::vector<std::thread> th;
-        th.reserve(n);
-        for (uint32_t r = 0; r < n; ++r) th.emplace_back([&, r] { rc[r] = f(r); });
+        bool spawn_failed = false;
+        try {
+            th.reserve(n);
+            for (uint32_t r = 0; r < n; ++r) th.emplace_back([&, r] { rc[r] = f(r); });
+        } catch (...) {
+            spawn_failed = true;
+        }
         for (std::thread& t : th) t.join();
+        if (spawn_failed) return gfail(g, PRT_ERR_HIP, "could not start a host thread per rank (%zu of %u started)", th.size(), n);
     }
     for (uint32_t r = 0; r < n; ++r)
         if (rc[r]) return gfail(g, rc[r], "rank %u (device %d): %s", r, g->devices[r], prt_last_error(g->ctx[r]));
@@ -251,7 +260,7 @@ int prt_group_set_scene(PrtGroup* g, const PrtSceneDesc* scene) {
 
 int prt_group_set_camera(PrtGroup* g, const PrtCameraDesc* cam) {
     if (!g) return PRT_ERR_INVALID;
-    return for_each_rank(g, [&](uint32_t r) { return prt_set_camera(g->ctx[r], cam); });
+    return for_each_rank(g, [&](uint32_t r) { return prt_set_camera(g->ctx[r], cam); }, false);
 }
 
 int prt_group_set_film(PrtGroup* g, uint32_t width, uint32_t height) {
@@ -279,22 +288,22 @@ int prt_group_set_film(PrtGroup* g, uint32_t width, uint32_t height) {
 int prt_group_film_clear(PrtGroup* g) {
     if (!g) return PRT_ERR_INVALID;
     g->film_current = false;
-    return for_each_rank(g, [&](uint32_t r) { return prt_film_clear(g->ctx[r]); });
+    return for_each_rank(g, [&](uint32_t r) { return prt_film_clear(g->ctx[r]); }, false);
 }
 
 int prt_group_set_sampling(PrtGroup* g, const PrtSampling* s) {
     if (!g) return PRT_ERR_INVALID;
-    return for_each_rank(g, [&](uint32_t r) { return prt_set_sampling(g->ctx[r], s); });
+    return for_each_rank(g, [&](uint32_t r) { return prt_set_sampling(g->ctx[r], s); }, false);
 }
 
 int prt_group_set_samples_in_flight(PrtGroup* g, uint32_t n_samples) {
     if (!g) return PRT_ERR_INVALID;
-    return for_each_rank(g, [&](uint32_t r) { return prt_set_samples_in_flight(g->ctx[r], n_samples); });
+    return for_each_rank(g, [&](uint32_t r) { return prt_set_samples_in_flight(g->ctx[r], n_samples); }, false);
 }
 
 int prt_group_set_param(PrtGroup* g, const char* name, int value) {
     if (!g) return PRT_ERR_INVALID;
-    return for_each_rank(g, [&](uint32_t r) { return prt_set_param(g->ctx[r], name, value); });
+    return for_each_rank(g, [&](uint32_t r) { return prt_set_param(g->ctx[r], name, value); }, false);
 }
 
 int prt_group_render(PrtGroup* g, uint32_t spp, uint32_t max_depth, uint32_t seed, uint32_t first_sample) {

@@ -70,14 +70,17 @@ def local_payload_tensor(renderer, device):
 class FilmGather:
     """Per-frame gather of the ranks' payloads to rank 0 and un-tiling into (rgb_sum, weight) tensors.
 
-    overlap = True (default): the frame's payload is SNAPSHOT on the render stream (one device-to-device copy of the
+    overlap = False (default): gather and un-tiling are enqueued on the CURRENT stream; the returned tensors can be consumed
+    on that stream right away (tonemap, read-back), as any torch result.
+    overlap = True (opt-in; what bench.py uses): the frame's payload is SNAPSHOT on the render stream (one device-to-device copy of the
     rank's tiles, 4 MB per GPU at 1080p / N = 8) and the gather + un-tiling run on a side stream from that snapshot, so
     the render stream goes straight on with the next frame (the gather is ~0.15-0.3 ms of an 8 ms step at N = 8).
-    The result tensors are complete once the side stream has been waited for: `wait()` (or torch.cuda.synchronize()).
+    With overlap the result tensors are written on the SIDE stream: a consumer on the current stream must call `wait()`
+    first (or torch.cuda.synchronize()); reading them without it races with the gather.
     always_collective = True runs the gather even with one rank (a 1-rank RCCL gather: the -m gpu test that makes
     init_process_group("nccl"), the zero-copy payload tensor and dist.gather execute on real hardware)."""
 
-    def __init__(self, renderer, device, group=None, overlap=True, always_collective=False):
+    def __init__(self, renderer, device, group=None, overlap=False, always_collective=False):
         import torch
         import torch.distributed as dist
         self.r = renderer

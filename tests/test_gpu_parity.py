@@ -888,3 +888,30 @@ def test_refit_rejects_another_topology_and_placed_copies():
     # the scene the renderer holds is untouched by the refused call
     o, d = _mesh_rays(np.random.default_rng(3), 500)
     assert util.hits_equal(r.closest_hit(o, d), util.oracle_scene(prt.scenes.mesh_scene(base)).closest_hit(o, d, use_bvh=False, n_threads=8)) == []
+
+
+def test_device_builder_copes_with_thousands_of_coincident_triangles():
+    """a run of clusters with identical boxes made PLOC's nearest-neighbour search merge ONE pair per pass (ties
+    to the lowest position), so > 8 k coincident triangles ran into the pass guard and a valid mesh was refused.  The
+    search now ranks pairs by a symmetric key (area, distance, parity, position): such a run halves per pass; and if a
+    device builder ever gives up, prt_set_scene falls back to the host builder instead of failing."""
+    n = 12_000
+    tri = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.2]], np.float32)
+    verts = np.tile(tri, (n, 1))
+    # (a few distinct triangles around them, so that the tree has something else to separate)
+    extra = np.random.default_rng(2).uniform(-1, 1, (300, 3)).astype(np.float32)
+    verts = np.concatenate([verts, extra])
+    idx = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(verts), 1))
+    mesh = prt.Mesh(vertices=verts, normals=nrm, indices=idx)
+    scene = prt.scenes.mesh_scene(mesh)
+    for mode in (1, 2):
+        r = prt.HipWavefrontRenderer(device=0)
+        r.set_param("gpu_build", mode)
+        film = prt.Film(16, 16)
+        r.Init(film, scene, prt.Camera(width=16, height=16))  # must not raise
+        assert r.bvh_info().n_nodes8 > 0
+        o, d = _mesh_rays(np.random.default_rng(4), 1500)
+        got = r.closest_hit(o, d)
+        want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
+        assert util.hits_equal(got, want) == []
