@@ -298,6 +298,11 @@ int prt_reset_stats(PrtContext* ctx);
 /* Runs ONE sample with the instrumented traversal kernel (film untouched) and fills
  * bvh_node_visits / bvh_tri_tests / prim_tests / rays_per_depth in `out`. */
 int prt_measure_traversal(PrtContext* ctx, uint32_t max_depth, uint32_t seed, uint32_t sample, PrtStats* out);
+/* Diagnostic (wavefront.md:92-93 "material-coherent queues"): runs one batch (film untouched) and reports, per
+ * bounce d, what the waves of the shade kernel find in their 64 ray slots by the material of the hit; out[16 * d + ...]:
+ * [0] waves, [1] lanes with a ray, [2 + t] lanes of material type t (0 = miss, 1..4 = PRT_MAT_*), [8 + t] waves holding type t,
+ * [14] sum over waves of distinct scattering types present, [15] waves with a scattering lane.  out: 16 * max_depth words. */
+int prt_measure_shade_divergence(PrtContext* ctx, uint32_t max_depth, uint32_t seed, uint32_t sample, uint64_t* out);
 int prt_bvh_info(PrtContext* ctx, PrtBvhInfo* out);
 int prt_kernel_occupancy(PrtContext* ctx, PrtOccupancy* out);
 /* Name of the traversal kernel instance the current scene and tunables select (what prt_render launches and what

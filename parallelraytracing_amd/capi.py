@@ -149,6 +149,7 @@ SIGNATURES = {
     "prt_bvh_info": (C.c_int, [_vp, C.POINTER(PrtBvhInfo)]),
     "prt_kernel_occupancy": (C.c_int, [_vp, C.POINTER(PrtOccupancy)]),
     "prt_kernel_instance": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    "prt_measure_shade_divergence": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "prt_refit_meshes": (C.c_int, [_vp, C.POINTER(PrtMesh), C.c_uint32]),
     "prt_bvh_read": (C.c_int, [_vp, _fp, _fp]),
     "prt_set_sampling": (C.c_int, [_vp, C.POINTER(PrtSampling)]),

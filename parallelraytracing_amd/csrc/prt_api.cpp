@@ -115,6 +115,7 @@ struct PrtContext {
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
     PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 1u};
+    unsigned long long* d_shade_div = nullptr;  // diagnostic (prt_measure_shade_divergence): 16 words per bounce, or null
     uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
     uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage
     size_t sort_entries = 0, sort_temp = 0;
@@ -410,6 +411,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             n_rays_known = c->h_counts[64 * (size_t)d] + c->h_counts[64 * (size_t)d + 32];
             if (n_rays_known == 0u) break;  // every path has ended: the later bounces have nothing to do
         }
+        if (c->d_shade_div) prt_launch_shade_divstats(c->stream, c->dsc, in, c->d_counts, d, n_paths, c->d_shade_div);
         if ((rc = begin_event(c, 2, &ep))) return rc;
         prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling,
                          n_rays_known, (compact && d == 0) ? &primary : nullptr);
@@ -1646,6 +1648,37 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     out->wave_cycles_refill = t[6];
     out->wave_cycles_node = t[7];
     out->wave_cycles_tri = t[8];
+    return PRT_OK;
+}
+
+// Diagnostic: one batch of measure_spp samples (film untouched) with k_shade_divstats in front of every k_shade.
+int prt_measure_shade_divergence(PrtContext* c, uint32_t max_depth, uint32_t seed, uint32_t sample, uint64_t* out) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!out || max_depth == 0 || max_depth > PRT_MAX_DEPTH) return PRT_ERR_INVALID;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = 16 * (size_t)PRT_MAX_DEPTH * sizeof(unsigned long long);
+    unsigned long long* buf = nullptr;
+    HIPCHECK(c, hipMalloc((void**)&buf, bytes));
+    hipError_t e = hipMemsetAsync(buf, 0, bytes, c->stream);
+    unsigned long long before[PRT_MAX_DEPTH];
+    if (e == hipSuccess) e = hipMemcpy(before, c->d_ray_stats, sizeof(before), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        c->d_shade_div = buf;
+        const bool timing = c->timing;
+        const uint64_t launches = c->stats.intersect_launches;
+        c->timing = false;
+        rc = run_batch(c, (uint32_t)std::max(1, c->measure_spp), max_depth, seed, sample, false, nullptr);
+        c->timing = timing;
+        c->stats.intersect_launches = launches;
+        c->d_shade_div = nullptr;
+        if (!rc) e = hipStreamSynchronize(c->stream);
+        if (!rc && e == hipSuccess) e = hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice);
+        if (!rc && e == hipSuccess) e = hipMemcpy(out, buf, 16 * (size_t)max_depth * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(buf);
+    if (rc) return rc;
+    HIPCHECK(c, e);
     return PRT_OK;
 }
 

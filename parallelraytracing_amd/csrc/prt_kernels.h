@@ -147,6 +147,9 @@ void prt_launch_intersect(hipStream_t st, const DevScene& sc, const PrtRayBuf& i
 void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const PrtRayBuf& out, float4* rad,
                       uint32_t* counts, uint32_t* work, uint32_t depth, uint32_t max_depth, uint32_t cap,
                       uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary = nullptr);
+// diagnostic: per-wave material mix of what k_shade of bounce `iter` is about to shade (16 words per bounce in `out`)
+void prt_launch_shade_divstats(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* counts, uint32_t iter,
+                               uint32_t cap, unsigned long long* out);
 // compact primary rays: per-pixel surface interaction of the primary hit (records 2n.. and 3n.. of `pix`), between the
 // first traversal and the first k_shade of a batch
 void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix);

@@ -2280,6 +2280,65 @@ __global__ void __launch_bounds__(256) k_primary_hit(DevScene sc, PrtPrimary pr,
     pix[3u * pr.n_pix_local + pl] = b;
 }
 
+// Diagnostic (prt_measure_shade_divergence, tools/shade_divergence.py; SURVEY 8f-4 "material-coherent work queues",
+// wavefront.md:92-93): what a wave of k_shade finds in its 64 ray slots, by the material of the hit.  Per bounce, 16 words:
+// [0] waves, [1] lanes with a ray, [2 + t] lanes whose hit has material type t (0 = miss / none, 1 Lambertian, 2 Metal,
+// 3 Dielectric, 4 Emissive), [8 + t] waves in which type t occurs, [14] sum over waves of the number of distinct SCATTERING
+// types (1..3) present, [15] waves with at least one scattering lane.  A wave executes the scatter code of every type it
+// holds, so [14] / [15] is the factor by which material divergence multiplies the scatter work.
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade_divstats(DevScene sc, const uint32_t* __restrict__ hit,
+                                                                 const uint32_t* __restrict__ counts, uint32_t iter, uint32_t cap,
+                                                                 unsigned long long* __restrict__ out) {
+    const uint32_t nA = CNT_A(counts, iter), nB = CNT_B(counts, iter);
+    const uint32_t count = nA + nB;
+    if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;
+    const uint32_t k = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
+    uint32_t type = 5u;  // no ray
+    if (k < count) {
+        const uint32_t src = k < nA ? k : cap - 1u - (k - nA);
+        const uint32_t id = hit[src];
+        type = 0u;
+        if (id != HIT_MISS && id != HIT_DEAD) {
+            uint32_t m;
+            if (id < sc.n_prims) {
+                m = sc.prims[id].material;
+            } else if (sc.n_insts) {
+                const uint32_t v = id - sc.n_prims;
+                uint32_t lo = 0, hi = sc.n_insts;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sc.insts[mid].virt_base <= v) lo = mid; else hi = mid;
+                }
+                const DevInstance& I = sc.insts[lo];
+                m = I.material == 0xFFFFFFFFu ? __float_as_uint(sc.tris[3 * (size_t)(I.slot_base + (v - I.virt_base)) + 1].w) : I.material;
+            } else {
+                m = __float_as_uint(sc.tris[3 * (size_t)(id - sc.n_prims) + 1].w);
+            }
+            type = sc.mat_type[m] <= 4u ? sc.mat_type[m] : 0u;
+        }
+    }
+    unsigned long long* o = out + 16u * iter;
+    const uint32_t lane = lane_id();
+    uint32_t distinct = 0u;
+    for (uint32_t t = 0; t < 5u; ++t) {
+        const unsigned long long mk = __ballot(type == t);
+        if (mk != 0ull && lane == 0u) {
+            atomicAdd(&o[2 + t], (unsigned long long)__popcll(mk));
+            atomicAdd(&o[8 + t], 1ull);
+        }
+        if (t >= 1u && t <= 3u && mk != 0ull) ++distinct;
+    }
+    const unsigned long long any = __ballot(type != 5u);
+    if (lane == 0u && any != 0ull) {
+        atomicAdd(&o[0], 1ull);
+        atomicAdd(&o[1], (unsigned long long)__popcll(any));
+        if (distinct) {
+            atomicAdd(&o[14], (unsigned long long)distinct);
+            atomicAdd(&o[15], 1ull);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Film accumulate (Film::AddSample, src/core/film.cu:37-55; BlitRadianceKernel + addBufferGPU,
 // renderer.cu:337-348, film.cu:79-88): samples are added in sample order, weight 1 each.
@@ -2724,6 +2783,11 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
         if (sa) PRT_SHADE(0, true, false, false); else PRT_SHADE(0, false, false, false);
     }
 #undef PRT_SHADE
+}
+
+void prt_launch_shade_divstats(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* counts, uint32_t iter,
+                               uint32_t cap, unsigned long long* out) {
+    hipLaunchKernelGGL(k_shade_divstats, dim3((cap + SHADE_BLOCK - 1u) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, sc, in.hit, counts, iter, cap, out);
 }
 
 void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix) {

@@ -461,6 +461,13 @@ class HipWavefrontRenderer:
         self._check(capi.lib().prt_refit_meshes(self._ctx, d.meshes, d.n_meshes))
         self._scene = scene
 
+    def measure_shade_divergence(self, sample: int = 0) -> np.ndarray:
+        """prt_measure_shade_divergence: [max_depth, 16] counters of the material mix per wave of the shade kernel."""
+        out = np.zeros((self.max_depth, 16), np.uint64)
+        self._check(capi.lib().prt_measure_shade_divergence(self._ctx, self.max_depth, self.seed, int(sample),
+                                                            out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
     def kernel_instance(self) -> str:
         """Name of the traversal kernel instance the scene and tunables select (prt_kernel_instance)."""
         buf = C.create_string_buffer(64)

@@ -21,3 +21,13 @@ for cfg in a.config.split(","):
     dt = time.perf_counter() - t0
     st = r.stats()
     print(f"{cfg} {W}x{H} depth {depth}: {a.calls / dt:.0f} ProgressiveRender() calls per second ({dt / a.calls * 1e3:.2f} ms each), {st.rays_total / dt / 1e6:.0f} Mrays/s", flush=True)
+    # where a call's time goes (HIP events around every launch; the events themselves add a little)
+    r.reset_stats()
+    r.enable_timing(True)
+    for _ in range(a.calls):
+        r.ProgressiveRender()
+    st = r.stats()
+    r.enable_timing(False)
+    n = a.calls
+    print(f"   per call, us: raygen {st.raygen_ms / n * 1e3:.0f}  traversal {st.intersect_ms / n * 1e3:.0f} ({st.intersect_launches / n:.0f} launches)  "
+          f"shade {st.shade_ms / n * 1e3:.0f}  accumulate {st.accumulate_ms / n * 1e3:.0f}  rays per depth {[int(st.rays_per_depth[d] // n) for d in range(depth)]}", flush=True)
