@@ -730,6 +730,15 @@ int prt_gpu_bvh8_build(hipStream_t st, const float* d_verts, const float* d_norm
     }
     level_begin[n_levels] = end;
     const uint32_t n_nodes = end;
+    {   // an unfinished tree (more than 63 levels) leaves `order` unfinished: stop before anything gathers through it
+        uint32_t chk[4];
+        GB_TRY(hipMemcpyAsync(chk, counters, sizeof(chk), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+        if (begin < end || chk[2] || chk[1] != n) {
+            cleanup(false);
+            return -3;
+        }
+    }
     // 4. boxes bottom-up, quantization, records
     for (uint32_t L = n_levels; L-- > 0;) {
         const uint32_t b = level_begin[L], e = level_begin[L + 1];
@@ -813,7 +822,11 @@ struct TopBuilder {
                 }
                 lc += ccnt[sorted[i]];
                 const double c = (double)ploc_half_area(lb) * lc + right_cost[i + 1];
-                if (c < best) {
+                // ties go to the split nearest the middle: clusters with IDENTICAL boxes (coincident triangles) make every
+                // split cost the same, and "first split wins" peeled one cluster off per level: a chain thousands of levels
+                // deep, far beyond the 63 levels the emission allows
+                const size_t mid = n / 2, di = i + 1 > mid ? i + 1 - mid : mid - (i + 1), db = best_split > mid ? best_split - mid : mid - best_split;
+                if (c < best || (c == best && di < db)) {
                     best = c;
                     best_axis = axis;
                     best_split = i + 1;
@@ -1025,15 +1038,19 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
         end = c4[0];
     }
     const uint32_t n_nodes = end;
-    hipLaunchKernelGGL(k_records, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, d_norms, d_tri_mat, order, n, n_prims, tris, nrms);
     uint32_t c4[4];
     GB_TRY(hipMemcpyAsync(c4, counters, sizeof(c4), hipMemcpyDeviceToHost, st));
     GB_TRY(hipStreamSynchronize(st));
     GB_TRY(hipGetLastError());
-    if (c4[2] || c4[1] != n) {
+    // a tree deeper than the 63 levels emitted above leaves `order` unfinished: stop BEFORE k_records gathers vertices
+    // through it (uninitialised entries would be wild indices: a memory fault, not an error code)
+    if (begin < end || c4[2] || c4[1] != n) {
         cleanup(false);
         return -3;
     }
+    hipLaunchKernelGGL(k_records, dim3((n + 255u) / 256u), dim3(256), 0, st, d_verts, d_norms, d_tri_mat, order, n, n_prims, tris, nrms);
+    GB_TRY(hipStreamSynchronize(st));
+    GB_TRY(hipGetLastError());
     cleanup(true);
     out->d_nodes8 = nodes8;
     out->d_tris = tris;
