@@ -114,7 +114,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 1u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 1u, 2500000u, 1u};
     unsigned long long* d_shade_div = nullptr;  // diagnostic (prt_measure_shade_divergence): 16 words per bounce, or null
     uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
     uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage
@@ -334,6 +334,27 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         return e != hipSuccess ? e : hipEventRecord(c->ev_counts[d], c->stream);
     };
     EventPair ep{};
+    // Small batches (the reference's contract: ONE sample per ProgressiveRender call, cpu/renderer.cpp:49): one launch of
+    // the PATH instance of the traversal kernel carries whole paths (prt_kernels.h PrtPathArgs) instead of raygen +
+    // 2 x max_depth launches that are each dominated by their ramp and their longest rays.  Same arithmetic, same
+    // draws, same rad[] / k_accumulate: the frame is bit-identical (tests run both routes).
+    const bool path_route = c->tune.path_kernel != 0u && (c->tune.path_kernel == 2u || S_cur == 1u) && n_paths <= c->tune.path_max &&
+                            !trav_stats && !c->d_shade_div && c->variant == 0 && fuse == 0u && c->sort_rays == 0u &&
+                            prt_path_kernel_applies(c->dsc, c->tune);
+    if (path_route) {
+        HIPCHECK(c, hipMemsetAsync(c->d_work, 0, 256 * sizeof(uint32_t), c->stream));  // the cursors; the error flags in [256] stay for prt_synchronize
+        PrtPathArgs pa{c->cam, c->tm, c->sampling, c->d_rad, first_sample, seed, max_depth, n_paths};
+        if ((rc = begin_event(c, 1, &ep))) return rc;
+        prt_launch_path(c->stream, c->dsc, pa, c->d_work, c->tune);
+        if ((rc = end_event(c, &ep))) return rc;
+        ++c->stats.intersect_launches;
+        if ((rc = begin_event(c, 3, &ep))) return rc;
+        prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats, nullptr);
+        if ((rc = end_event(c, &ep))) return rc;
+        if (accumulate) c->stats.samples += S_cur;
+        HIPCHECK(c, hipGetLastError());
+        return PRT_OK;
+    }
     // front/back counters of every bounce start at zero (the producers add to them atomically)
     HIPCHECK(c, hipMemsetAsync(c->d_counts, 0, (size_t)(max_depth + 1) * PRT_CNT_STRIDE * sizeof(uint32_t), c->stream));
     // compact primary rays (PrtPrimary): the default pipeline without jitter / roulette / clamp / fusion
@@ -1751,6 +1772,8 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "exact_grids" && (value == 0 || value == 1 || value == 2)) c->tune.exact_grids = (uint32_t)value;
     else if (n == "steal" && value >= 0 && value <= 64) c->tune.steal = (uint32_t)value;
     else if (n == "primary_hit" && (value == 0 || value == 1)) c->tune.primary_hit = (uint32_t)value;
+    else if (n == "path_kernel" && value >= 0 && value <= 2) c->tune.path_kernel = (uint32_t)value;
+    else if (n == "path_max" && value >= 1) c->tune.path_max = (uint32_t)value;
     else if (n == "sort_rays" && value >= 0 && value <= 2) c->sort_rays = (uint32_t)value;
     else if (n == "compact_primary" && (value == 0 || value == 1)) c->compact_primary = value;
     else if (n == "node_stride" && (value == 0 || value == 5 || value == 8)) c->node_stride = value;

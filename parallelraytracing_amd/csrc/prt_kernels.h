@@ -92,6 +92,8 @@ struct PrtTravTuning {
     uint32_t tail;         // 8-wide kernel: the last `tail` 64-ray granules per resident wave are handed out one at a time
     uint32_t probe_slot;   // instrumented instance only: this launch's timeline goes to stats[16 + 8 * probe_slot ..] (see PRT_TIMELINE)
     const uint32_t* perm;  // measurement aid (sort_rays): the 8-wide kernel takes ray perm[i] where it would take ray i (nullptr = identity)
+    uint32_t path_kernel;  // host: 1 = a batch of ONE sample with at most path_max paths runs as one launch of the path instance of the 8-wide kernel (below); 2 = any batch of at most path_max paths; 0 = off
+    uint32_t path_max;
     uint32_t primary_hit;  // host: with compact primary rays, rebuild the primary hit's surface interaction once per pixel (k_primary_hit); 0 = per sample in k_shade (A/B)
 };
 
@@ -127,6 +129,18 @@ struct PrtPrimary {
     uint32_t first_sample, seed;
 };
 
+// The PATH instance of k_traverse8_persistent (small batches: the reference's one sample per ProgressiveRender call): ONE
+// persistent launch carries whole paths.  A lane generates its path's primary ray, walks it, shades the hit when the walk is
+// over (advance_path, the code of k_shade) and goes on with the scattered ray, until the path ends (rad[path] written) and
+// the lane takes the next path.  What the launch needs beyond the scene:
+struct PrtPathArgs {
+    DevCamera cam;
+    PrtTileMap tm;
+    PrtSampling sp;
+    float4* rad;
+    uint32_t first_sample, seed, max_depth, n_paths;
+};
+
 #define PRT_CNT_STRIDE 64u  // uint32 per bounce in the counter array: [0] front, [32] back, [16] finished-in-producer counts
 
 void prt_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PrtTileMap& tm, uint32_t n_paths,
@@ -137,6 +151,9 @@ void prt_launch_scan_prims(hipStream_t st, const DevScene& sc, const PrtRayBuf& 
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
                          const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary = nullptr);
+// one launch for a whole batch of paths (PrtPathArgs); `work` (cursors + error flags) must have been zeroed on the stream
+void prt_launch_path(hipStream_t st, const DevScene& sc, const PrtPathArgs& pa, uint32_t* work, const PrtTravTuning& tune);
+bool prt_path_kernel_applies(const DevScene& sc, const PrtTravTuning& tune);
 // true if prt_launch_traverse would run the instance that can rebuild compact primary rays (and needs no overflow list)
 bool prt_traverse_takes_primary(const DevScene& sc, const PrtTravTuning& tune);
 int prt_traverse_occupancy(const DevScene& sc, const PrtTravTuning& tune, int* blocks_per_cu, int* vgprs, int* sgprs, int* lds_bytes);

@@ -1611,7 +1611,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse4_persistent(DevScene sc
     T8_HALF(w1.w, nxb, fxb, nyb, fyb, nzb, fzb)
 
 #define T8_SENTINEL 0xFFFFFFFFu
-template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false, bool PRIM = false>
+template <int STACK_L, int WAVES, bool STATS, bool INST, bool LEAN = false, bool PRIM = false, bool PATH = false>
 __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc, const float4* __restrict__ ro,
                                                                     const float4* __restrict__ rd,
                                                                     uint32_t* __restrict__ hit,
@@ -1619,8 +1619,16 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                                                                     const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ work,
                                                                     uint32_t* __restrict__ ovf, PrtTravTuning tune,
-                                                                    unsigned long long* __restrict__ stats, PrtPrimary pr) {
+                                                                    unsigned long long* __restrict__ stats, PrtPrimary pr,
+                                                                    PrtPathArgs pa) {
     // PRIM: the rays are compact primary rays (PrtPrimary): origin and direction are rebuilt from the path id
+    // PATH (PrtPathArgs, prt_kernels.h): the work items are whole PATHS, not rays.  A lane whose walk is over is not
+    // released: it waits (need_shade) until refill_min lanes of the wave wait or are idle, then those lanes run the shade
+    // step together (advance_path: the body of k_shade, same draws in the same order) and walk the scattered ray next; a
+    // segment that cannot hit a triangle is shaded on the spot, as the producers' classification decides it; idle lanes
+    // take new paths from the launch's cursor and generate their primary ray (k_raygen's arithmetic).  One launch per
+    // batch instead of 2 x max_depth + 1: a small batch's launches are dominated by their ramp and their longest rays
+    // (C3, one sample: 5 traversal launches of ~150 us for ~30 us of work each), which this pays once.
     __shared__ uint2 s_stack[(STACK_L + 1) * 256];  // [entry][thread]; one row of slack above the top
     __shared__ unsigned long long s_key[256];       // per lane: best (d2 bits << 32 | prim) of the cooperative triangle tests
     __shared__ uint32_t s_slot[256];                // per lane: leaf-order slot of that best
@@ -1646,7 +1654,14 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // (No LDS for the bookkeeping: one more KB would cost the fifth block per CU.  Which roots still have helpers is a
     // wave-uniform 64-bit mask rebuilt from the helpers' k every outer iteration of a draining wave.)
     constexpr bool STEAL = LEAN && !INST;
-    const uint32_t count = *count_ptr;
+    static_assert(!PATH || (!LEAN && !INST && !PRIM && !STATS), "the path instance is the plain one-level kernel");
+    const uint32_t count = PATH ? pa.n_paths : *count_ptr;
+    // PATH: the path a busy lane carries (k = its path id): direction as stored (the walk normalises it again, as the
+    // reference's TransformNormal does), throughput, RNG state, segment index; need_shade: the walk of the current
+    // segment is over, best.id is its closest hit
+    f3 pd = mk3(0.f, 0.f, 1.f), pthr = mk3(0.f, 0.f, 0.f);
+    uint32_t prng = 0u, pdepth = 0u;
+    bool need_shade = false;
     // (tune.stack_cap: test hook that makes the stack look shorter, to exercise the overflow path)
     const int stack_cap = (tune.stack_cap != 0u && tune.stack_cap < (uint32_t)STACK_L) ? (int)tune.stack_cap : STACK_L;
     // Guided hand-out of the ray buffer, in granules of 64 rays.  The bulk goes out in chunks of tune.chunk rays (one
@@ -1718,7 +1733,10 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
         // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
         if (k != 0xFFFFFFFFu && !pending && !(INST && (in_blas || ipm != 0u))) {
             if (overflow) {
-                if (INST) {
+                if (PATH) {  // (the host only uses this instance for trees its stack holds: an error prt_synchronize reports)
+                    atomicOr(work + 256, 2u);
+                    need_shade = true;
+                } else if (INST) {
                     atomicOr(work + 256, 2u);  // no fallback for two-level scenes: prt_synchronize reports it
                 } else {
                     const uint32_t j = atomicAdd(ovf, 1u);  // re-done from scratch by the spill-capable 4-wide instance
@@ -1728,9 +1746,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         atomicOr(work + 256, 2u);
                 }
                 overflow = false;
-                k = 0xFFFFFFFFu;
+                if (!PATH) k = 0xFFFFFFFFu;
             } else if (!(gy > 0x00FFFFFFu) && sp == 0) {
-                if (STEAL && k >= 0xFFFFFF00u) {  // a helper (k = 0xFFFFFF00 | root lane): its subtree is done
+                if (PATH) {
+                    need_shade = true;  // the lane keeps its path; the shade step below goes on with it
+                } else if (STEAL && k >= 0xFFFFFF00u) {  // a helper (k = 0xFFFFFF00 | root lane): its subtree is done
                     k = 0xFFFFFFFFu;
                 } else if (!STEAL || ((helped >> lane) & 1ull) == 0ull) {
                     hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
@@ -1869,7 +1889,97 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 stall = false;
             }
         }
-        if (!exhausted && (n_idle >= tune.refill_min || (INST && do_sw && n_idle != 0u))) {
+        if (PATH) {
+            // The shade step of the waiting lanes and new paths for the idle ones, together: when refill_min lanes wait or
+            // are idle, or when no lane of the wave has anything left to walk or to test.
+            const unsigned long long shade_m = __ballot(need_shade);
+            const uint32_t n_wait = n_idle + (uint32_t)__popcll(shade_m);
+            const bool others_busy = __ballot(k != 0xFFFFFFFFu && !need_shade) != 0ull;
+            if ((shade_m != 0ull || (!exhausted && n_idle != 0u)) && (n_wait >= tune.refill_min || !others_busy)) {
+                bool fresh = false;
+                if (!exhausted && n_idle != 0u) {
+                    if (cur == cur_end) {  // grab the next chunk / granule of path ids (as the ray hand-out above)
+                        uint32_t c = blockIdx.x * 4u + wv;
+                        if (!first_grab) {
+                            if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
+                            c = (uint32_t)__shfl((int)c, 0, 64);
+                        }
+                        first_grab = false;
+                        if (c >= n_grabs) {
+                            exhausted = true;
+                        } else {
+                            const uint32_t g0 = c < n_bulk ? c * gran_per_chunk : n_bulk * gran_per_chunk + (c - n_bulk);
+                            const uint32_t g1 = c < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
+                            cur = g0 << 6;
+                            cur_end = (g1 << 6) < count ? (g1 << 6) : count;
+                        }
+                    }
+                    if (!exhausted) {
+                        const uint32_t qi = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                        fresh = idle && qi < cur_end;
+                        if (fresh) k = qi;
+                        cur = (cur + n_idle < cur_end) ? cur + n_idle : cur_end;
+                    }
+                }
+                // r: 0 = the path has ended (rad written), 1 = walk (o, pd) from its analytic hit (id0, d2_0),
+                //    2 = shade hit `id` of the segment (o, pd) next
+                int r = 0;
+                uint32_t id = HIT_MISS, id0 = HIT_MISS;
+                float d2_0 = 3.402823466e+38f;
+                if (fresh) {  // k_raygen's arithmetic for path k = sample * n_pix_local + local pixel
+                    const uint32_t smp = k / pa.tm.n_pix_local, pl = k - smp * pa.tm.n_pix_local;
+                    uint32_t px, py;
+                    if (!tile_pixel(pa.tm, pl, px, py)) {  // a partial tile's pixel outside the image: no path
+                        pa.rad[k] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+                    } else {
+                        prng = path_seed(py * pa.tm.W + px, pa.first_sample + smp, pa.seed);
+                        float fx = (float)px + 0.5f, fy = (float)py + 0.5f;  // pixel centre (cpu/renderer.cpp:45)
+                        if (pa.sp.jitter) {  // (x + u1, y + u2): the path's first two draws (optix/device_programs.cu:172-173)
+                            const float u1 = rnd01(prng);
+                            const float u2 = rnd01(prng);
+                            fx = (float)px + u1;
+                            fy = (float)py + u2;
+                        }
+                        camera_ray(pa.cam, fx, fy, o, pd);
+                        pthr = mk3(1.f, 1.f, 1.f);
+                        pdepth = 0u;
+                        r = classify_ray<false, 256>(sc, o, pd, id0, d2_0) ? 1 : 2;
+                        id = id0;
+                    }
+                }
+                if (need_shade) {
+                    r = 2;
+                    id = best.id;
+                    need_shade = false;
+                }
+                while (r == 2) {  // (a segment that cannot hit a triangle is shaded right away: its hit is the analytic one)
+                    r = advance_path<1, false, false, 256>(sc, id, o, pd, pthr, prng, pdepth, pa.max_depth, pa.sp, &pa.rad[k], id0, d2_0);
+                    id = id0;
+                }
+                if (r == 1) {  // start the walk of (o, pd): the set-up of a refill
+                    ld = normalize3(pd);  // TransformNormal(identity, d), primitive.cpp:30
+                    pad = sc.pad * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) + sc.extent);
+                    ix = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.x) < 1e-30f ? __builtin_copysignf(1e-30f, ld.x) : ld.x);
+                    iy = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.y) < 1e-30f ? __builtin_copysignf(1e-30f, ld.y) : ld.y);
+                    iz = __builtin_amdgcn_rcpf(__builtin_fabsf(ld.z) < 1e-30f ? __builtin_copysignf(1e-30f, ld.z) : ld.z);
+                    const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+                    anx = (nx ? o.x - pad : o.x + pad) * ix; afx = (nx ? o.x + pad : o.x - pad) * ix;
+                    any = (ny ? o.y - pad : o.y + pad) * iy; afy = (ny ? o.y + pad : o.y - pad) * iy;
+                    anz = (nz ? o.z - pad : o.z + pad) * iz; afz = (nz ? o.z + pad : o.z - pad) * iz;
+                    octinv4 = (7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u))) * 0x01010101u;
+                    best.id = id0;
+                    best.prim = id0;  // analytic index, or 0xFFFFFFFF for a miss
+                    best.d2 = d2_0;
+                    tlimit = limit_from_d2(best.d2, pad);
+                    gx = 0u;  // the root "group": node 0, one pending hit that decodes to slot 0
+                    gy = 1u << (24u + (octinv4 & 7u));
+                    sp = 0;
+                } else if ((fresh || ((shade_m >> lane) & 1ull)) && r == 0) {
+                    k = 0xFFFFFFFFu;  // the path is over: the lane is idle again
+                }
+            }
+        }
+        if (!PATH && !exhausted && (n_idle >= tune.refill_min || (INST && do_sw && n_idle != 0u))) {
             if (cur == cur_end) {  // grab the next chunk / granule
                 uint32_t c = blockIdx.x * 4u + wv;
                 if (!first_grab) {
@@ -2352,10 +2462,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
     // primary ray (w != 0xFFFFFFFE); those S identical values are not in rad[] and are added from the record.
     // rad[path] = {radiance, index of the path's last segment}.  Ray segments at depth d = paths whose last segment
     // index is >= d: a per-block histogram of the last indices (wave ballots -> LDS) gives the per-depth counts.
+    // A block takes several groups of 256 pixels (grid-stride): its per-depth counts reach the global counters with ONE
+    // atomic per depth per block, and a counter word only executes ~87 atomics per microsecond (tools/atomic_rate.hip): with
+    // one block per 256 pixels a 1080p frame was 8,100 atomics per word = 93 us, most of a one-sample k_accumulate.
     __shared__ uint32_t s_ends[PRT_MAX_DEPTH];
     if (threadIdx.x < PRT_MAX_DEPTH) s_ends[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t pl0 = blockIdx.x * 256u; pl0 < tm.n_pix_local; pl0 += gridDim.x * 256u) {  // block-uniform trip count
+    const uint32_t pl = pl0 + threadIdx.x;
     uint32_t x, y;
     const bool valid = pl < tm.n_pix_local && tile_pixel(tm, pl, x, y);
     float4 f = valid ? film_local[pl] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2390,6 +2504,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
         }
     }
     if (valid && update_film) film_local[pl] = f;
+    }
     __syncthreads();
     if (threadIdx.x < max_depth) {
         unsigned long long n = 0;
@@ -2641,10 +2756,10 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
     do {                                                                                                           \
         if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, true, IN>), grid, block, 0, st, sc, in.o, in.d,       \
-                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{});                   \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{}, PrtPathArgs{});    \
         else                                                                                                       \
             hipLaunchKernelGGL((k_traverse8_persistent<L, W, false, IN>), grid, block, 0, st, sc, in.o, in.d,      \
-                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{});                   \
+                               in.hit, in.hd2, count_ptr, work, ovf, tune, stats, PrtPrimary{}, PrtPathArgs{});    \
     } while (0)
         if (kind == T8_INST12_4) {  // placed mesh copies: two-level walk; a stack overflow is an error (the host checks the depths).
             // 12 stack entries + the lanes' world rays in LDS = the same 40 KB per block as the one-level instance
@@ -2665,16 +2780,16 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
             if (tune.stack_cap != 0u || sc.depth8 > stack_l + 1u) t5.steal = 0u;  // (a helper cannot hand a ray to the overflow list)
             if (stats && primary)
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary, PrtPathArgs{});
             else if (stats)
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, true, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{});
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{}, PrtPathArgs{});
             else if (primary)  // bounce 0 of a batch whose k_raygen stored compact primary rays
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary);
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, *primary, PrtPathArgs{});
             else
                 hipLaunchKernelGGL((k_traverse8_persistent<8, 5, false, false, true>), grid5, block, 0, st, sc, in.o, in.d,
-                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{});
+                                   in.hit, in.hd2, count_ptr, work, ovf, t5, stats, PrtPrimary{}, PrtPathArgs{});
         } else {
             PRT_LAUNCH_8(15, 4, false);
         }
@@ -2718,6 +2833,21 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
         else PRT_LAUNCH_T(k_traverse_persistent, 31, 5, 1, grid, count_ptr, no_list);
     }
 #undef PRT_LAUNCH_T
+}
+
+// The PATH instance (PrtPathArgs): whole paths in one launch, for small batches.  One-level scenes with the 8-wide tree,
+// a tree its 15-entry stack holds, and no primitive BVH (classify_ray's walk keeps a per-thread LDS stack of its own).
+bool prt_path_kernel_applies(const DevScene& sc, const PrtTravTuning& tune) {
+    return sc.nodes8 && !sc.n_insts && !sc.abvh_nodes && sc.depth8 <= 16u && tune.wide == 2u && tune.stack_cap == 0u;
+}
+void prt_launch_path(hipStream_t st, const DevScene& sc, const PrtPathArgs& pa, uint32_t* work, const PrtTravTuning& tune) {
+    uint32_t g = tune.grid_blocks;
+    const uint32_t need_blocks = blocks_for(pa.n_paths);
+    if (g > need_blocks) g = need_blocks;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL((k_traverse8_persistent<15, 4, false, false, false, false, true>), dim3(g), dim3(256), 0, st, sc, (const float4*)nullptr,
+                       (const float4*)nullptr, (uint32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, work, work + 512, tune,
+                       (unsigned long long*)nullptr, PrtPrimary{}, pa);
 }
 
 // Static occupancy of the default traversal kernel instance for this scene (what the wavefront-occupancy figure of
@@ -2796,8 +2926,9 @@ void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats, const float4* pix_end) {
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(tm.n_pix_local ? tm.n_pix_local : 1)), dim3(256), 0, st, rad,
-                       film_local, tm, S, max_depth, update_film ? 1 : 0, ray_stats, pix_end);
+    const uint32_t nb = blocks_for(tm.n_pix_local ? tm.n_pix_local : 1);
+    hipLaunchKernelGGL(k_accumulate, dim3(nb < 2048u ? nb : 2048u), dim3(256), 0, st, rad, film_local, tm, S, max_depth,
+                       update_film ? 1 : 0, ray_stats, pix_end);
 }
 
 void prt_launch_resolve(hipStream_t st, const float4* gathered, uint32_t world, uint32_t stride, uint32_t W,

@@ -91,6 +91,8 @@ def run_case(case, seed):
         params["compact_primary"] = 0
     if rng.random() < 0.2:
         params["primary_hit"] = 0
+    if rng.random() < 0.4:
+        params["path_kernel"] = int(rng.choice([0, 2]))  # (1 = the default: batches of one sample)
     if rng.random() < 0.3:
         params["fuse"] = int(rng.integers(0, 2))
     if rng.random() < 0.2:
@@ -261,7 +263,8 @@ def run_sequence_case(case, seed):
         elif op == "param":
             name, val = [("fuse", int(rng.integers(0, 2))), ("exact_grids", int(rng.integers(0, 3))), ("refill_min", int(rng.choice([1, 16, 64]))),
                          ("tri_min", int(rng.choice([1, 24, 64]))), ("compact_primary", int(rng.integers(0, 2))), ("steal", int(rng.choice([0, 8]))),
-                         ("primary_hit", int(rng.integers(0, 2)))][int(rng.integers(0, 7))]
+                         ("primary_hit", int(rng.integers(0, 2))),
+                         ("path_kernel", int(rng.integers(0, 3)))][int(rng.integers(0, 8))]
             r.set_param(name, val)
             log.append(f"{name}={val}")
         else:

@@ -915,3 +915,58 @@ def test_device_builder_copes_with_thousands_of_coincident_triangles():
         got = r.closest_hit(o, d)
         want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=False, n_threads=8)
         assert util.hits_equal(got, want) == []
+
+
+# ---- the PATH instance of the traversal kernel: whole paths in one launch (small batches, one sample per call) -------------
+@pytest.mark.parametrize("sampling", [None, {"jitter": 1}, {"jitter": 1, "rr_depth": 2, "clamp": 4.0}])
+@pytest.mark.parametrize("mode", ["one-sample-calls", "forced-batch"])
+def test_path_kernel_frames_are_bit_exact(mode, sampling):
+    """prt_set_param("path_kernel", 1): a batch of ONE sample runs as a single launch in which every lane carries a whole path
+    (primary ray, walks, shade steps); 2: any small batch.  The frame must equal the oracle's (throughput form) and the frame
+    of the raygen / traverse / shade pipeline bit for bit, with the ray counts."""
+    mesh = prt.scenes.refined("bunny.ply", 30_000)
+    scene = prt.scenes.mesh_scene(mesh)
+    W, H, spp, depth = 120, 68, 3, 6
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    frames = {}
+    for pk in (0, 1 if mode == "one-sample-calls" else 2):
+        r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=11, cam=cam)
+        r.set_param("path_kernel", pk)
+        sp = r.set_sampling(**sampling) if sampling else None
+        if mode == "one-sample-calls":
+            for _ in range(spp):
+                r.ProgressiveRender()  # one sample per call: the reference's contract
+        else:
+            r.ProgressiveRender(spp)
+        r.download()
+        st = r.stats()
+        frames[pk] = (film.accum.copy(), film.weights.copy(), int(st.rays_total), [int(st.rays_per_depth[d]) for d in range(depth)])
+    a, b = frames[0], frames[1 if mode == "one-sample-calls" else 2]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    osc = util.oracle_scene(scene)
+    acc, wts, rays = osc.render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=11, iterative=True, use_bvh=True, n_threads=8, sampling=sp)
+    assert np.array_equal(b[0], acc) and np.array_equal(b[1], wts) and b[2] == rays
+
+
+def test_path_kernel_partial_tiles_and_partition():
+    """A frame whose size is not a multiple of the 8x8 tiles, rendered by three contexts (ranks) one sample per call: the
+    path instance must leave out-of-image pixels of partial tiles alone and honour the tile map."""
+    mesh = prt.scenes.refined("bunny.ply", 12_000)
+    scene = prt.scenes.mesh_scene(mesh)
+    W, H, spp, depth = 53, 37, 2, 5
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    osc = util.oracle_scene(scene)
+    acc, wts, rays = osc.render(cam.desc(), W, H, spp=spp, max_depth=depth, seed=2, iterative=True, use_bvh=True, n_threads=8)
+    total = np.zeros_like(acc)
+    n_rays = 0
+    for rank in range(3):
+        film = prt.Film(W, H)
+        r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=2, rank=rank, world_size=3)
+        r.Init(film, scene, cam)
+        r.set_param("path_kernel", 1)
+        for _ in range(spp):
+            r.ProgressiveRender()
+        r.download()
+        total += film.accum
+        n_rays += int(r.stats().rays_total)
+    assert np.array_equal(total, acc) and n_rays == rays
