@@ -114,7 +114,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 1u, 2500000u, 1u};
+    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 0u, 2500000u, 1u};
     unsigned long long* d_shade_div = nullptr;  // diagnostic (prt_measure_shade_divergence): 16 words per bounce, or null
     uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
     uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage
@@ -334,10 +334,12 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         return e != hipSuccess ? e : hipEventRecord(c->ev_counts[d], c->stream);
     };
     EventPair ep{};
-    // Small batches (the reference's contract: ONE sample per ProgressiveRender call, cpu/renderer.cpp:49): one launch of
-    // the PATH instance of the traversal kernel carries whole paths (prt_kernels.h PrtPathArgs) instead of raygen +
-    // 2 x max_depth launches that are each dominated by their ramp and their longest rays.  Same arithmetic, same
-    // draws, same rad[] / k_accumulate: the frame is bit-identical (tests run both routes).
+    // Small batches (the reference's contract: ONE sample per ProgressiveRender call, cpu/renderer.cpp:49) can run as one
+    // launch of the PATH instance of the traversal kernel, which carries whole paths (prt_kernels.h PrtPathArgs), instead
+    // of raygen + 2 x max_depth launches.  Same arithmetic, same draws, same rad[] / k_accumulate: the frame is
+    // bit-identical (tests run both routes).  OFF by default (prt_set_param("path_kernel", 1 | 2)): measured, it ties with
+    // the pipeline up to ~250 k paths per call and loses above (profiles/r3_path_kernel.txt, TUNING.md): both are bound
+    // by a path's chain of dependent node fetches, and the pipeline shades with full waves.
     const bool path_route = c->tune.path_kernel != 0u && (c->tune.path_kernel == 2u || S_cur == 1u) && n_paths <= c->tune.path_max &&
                             !trav_stats && !c->d_shade_div && c->variant == 0 && fuse == 0u && c->sort_rays == 0u &&
                             prt_path_kernel_applies(c->dsc, c->tune);

@@ -92,7 +92,7 @@ struct PrtTravTuning {
     uint32_t tail;         // 8-wide kernel: the last `tail` 64-ray granules per resident wave are handed out one at a time
     uint32_t probe_slot;   // instrumented instance only: this launch's timeline goes to stats[16 + 8 * probe_slot ..] (see PRT_TIMELINE)
     const uint32_t* perm;  // measurement aid (sort_rays): the 8-wide kernel takes ray perm[i] where it would take ray i (nullptr = identity)
-    uint32_t path_kernel;  // host: 1 = a batch of ONE sample with at most path_max paths runs as one launch of the path instance of the 8-wide kernel (below); 2 = any batch of at most path_max paths; 0 = off
+    uint32_t path_kernel;  // host: 0 = off (default); 1 = a batch of ONE sample with at most path_max paths runs as one launch of the path instance of the 8-wide kernel (below); 2 = any batch of at most path_max paths
     uint32_t path_max;
     uint32_t primary_hit;  // host: with compact primary rays, rebuild the primary hit's surface interaction once per pixel (k_primary_hit); 0 = per sample in k_shade (A/B)
 };
