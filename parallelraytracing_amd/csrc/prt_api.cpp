@@ -114,7 +114,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 16u, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 0u, 2500000u, 1u};
+    PrtTravTuning tune{1024u, 256u, 16u, 0xFFFFFFFFu /* exit_max: auto */, 0u, 2u, 24u, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 0u, 2500000u, 1u};
     unsigned long long* d_shade_div = nullptr;  // diagnostic (prt_measure_shade_divergence): 16 words per bounce, or null
     uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
     uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage

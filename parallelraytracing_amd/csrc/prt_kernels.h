@@ -80,7 +80,7 @@ struct PrtTravTuning {
     uint32_t grid_blocks;  // resident 256-thread blocks of the persistent grid
     uint32_t chunk;        // rays a wave grabs per global atomic (multiple of 64)
     uint32_t refill_min;   // idle lanes of a wave that trigger a refill
-    uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf
+    uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf (0xFFFFFFFF = per instance: 32 two-level, 16 otherwise)
     uint32_t xcd_affinity; // 4-wide / binary kernels, A/B: 1 = each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
     uint32_t wide;         // 2: walk the compressed 8-wide tree (default), 1: the 4-wide tree, 0: the binary tree
     uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles

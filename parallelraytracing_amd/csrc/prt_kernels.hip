@@ -2722,13 +2722,18 @@ const char* prt_traverse_instance(const DevScene& sc, const PrtTravTuning& tune)
 
 void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* count_ptr,
                          uint32_t* work, uint32_t* spill, uint32_t max_rays, uint32_t tree_depth, uint32_t stack4,
-                         const PrtTravTuning& tune, unsigned long long* stats, const PrtPrimary* primary) {
+                         const PrtTravTuning& tune_in, unsigned long long* stats, const PrtPrimary* primary) {
+    // exit_max "auto" (0xFFFFFFFF, the context's default): the two-level instance leaves its node loop at <= 32 walkers
+    // (its lanes wait for level switches that the wave does together; C5I +4.4 % against 16, gpurun_out/r3_sweep_C5I_b.log),
+    // every other instance at <= 16
+    PrtTravTuning tune = tune_in;
+    if (tune.exit_max == 0xFFFFFFFFu) tune.exit_max = t8_kind(sc, tune_in) == T8_INST12_4 ? 32u : 16u;
 #ifdef PRT_PROBE_REBOUND
     // diagnostic build (tools/bounce_stats.py --rebound): the instrumented launch is preceded by a plain one that leaves
     // every ray's FINAL hit distance as its initial culling bound, so the instrumented walk's visit counts are those of a
     // traversal that knew the answer from the start: the floor for any visiting order / triangle-test schedule
     if (stats) {
-        prt_launch_traverse(st, sc, in, count_ptr, work, spill, max_rays, tree_depth, stack4, tune, nullptr, primary);
+        prt_launch_traverse(st, sc, in, count_ptr, work, spill, max_rays, tree_depth, stack4, tune_in, nullptr, primary);
         hipLaunchKernelGGL(k_reset_cursors, dim3(1), dim3(64), 0, st, work);
     }
 #endif
@@ -2840,7 +2845,9 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
 bool prt_path_kernel_applies(const DevScene& sc, const PrtTravTuning& tune) {
     return sc.nodes8 && !sc.n_insts && !sc.abvh_nodes && sc.depth8 <= 16u && tune.wide == 2u && tune.stack_cap == 0u;
 }
-void prt_launch_path(hipStream_t st, const DevScene& sc, const PrtPathArgs& pa, uint32_t* work, const PrtTravTuning& tune) {
+void prt_launch_path(hipStream_t st, const DevScene& sc, const PrtPathArgs& pa, uint32_t* work, const PrtTravTuning& tune_in) {
+    PrtTravTuning tune = tune_in;
+    if (tune.exit_max == 0xFFFFFFFFu) tune.exit_max = 16u;
     uint32_t g = tune.grid_blocks;
     const uint32_t need_blocks = blocks_for(pa.n_paths);
     if (g > need_blocks) g = need_blocks;

@@ -28,11 +28,11 @@ CSRC = os.path.join(ROOT, "parallelraytracing_amd", "csrc")
 
 # template arguments <STACK_L, WAVES, STATS, INST, LEAN, PRIM> as they appear in the mangled names
 INSTANCES = {
-    "lean8_5waves": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb0EE",        # default: trees of <= 9 levels (C2, C3, C4)
-    "lean8_5waves_primary": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb1EE",  # the same reading compact primary rays (bounce 0)
-    "deep15_4waves": "k_traverse8_persistentILi15ELi4ELb0ELb0ELb0ELb0EE",       # deeper device-built trees (no 4-wide fallback)
-    "wide11_5waves": "k_traverse8_persistentILi11ELi5ELb0ELb0ELb0ELb0EE",       # A/B (stack_lds = 5)
-    "inst12_4waves": "k_traverse8_persistentILi12ELi4ELb0ELb1ELb0ELb0EE",       # placed copies (C5I)
+    "lean8_5waves": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb0ELb0EE",        # default: trees of <= 9 levels (C2, C3, C4)
+    "lean8_5waves_primary": "k_traverse8_persistentILi8ELi5ELb0ELb0ELb1ELb1ELb0EE",  # the same reading compact primary rays (bounce 0)
+    "deep15_4waves": "k_traverse8_persistentILi15ELi4ELb0ELb0ELb0ELb0ELb0EE",       # deeper device-built trees (no 4-wide fallback)
+    "wide11_5waves": "k_traverse8_persistentILi11ELi5ELb0ELb0ELb0ELb0ELb0EE",       # A/B (stack_lds = 5)
+    "inst12_4waves": "k_traverse8_persistentILi12ELi4ELb0ELb1ELb0ELb0ELb0EE",       # placed copies (C5I)
 }
 
 
