@@ -72,15 +72,25 @@ def newest_profile(pattern, match):
     return best
 
 
+def kernel_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_sha import kernel_sha as f
+        return f()
+    except Exception:
+        return None
+
+
 def isa_counts(instance):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_isa_counts.json")), reverse=True):
         try:
-            e = json.load(open(f))["instances"][instance]
+            j = json.load(open(f))
+            e = j["instances"][instance]
             return {"node_step": int(e["node_step"]["valu"]), "triangle_round": int(e["triangle_round"]["valu"]),
-                    "source": os.path.basename(f)}
+                    "source": os.path.basename(f), "kernel_sha16": j.get("kernel_sha16")}
         except Exception:
             continue
-    return dict(VALU_FALLBACK, source="bench.py VALU_FALLBACK")
+    return dict(VALU_FALLBACK, source="bench.py VALU_FALLBACK", kernel_sha16=None)
 
 
 def parse():
@@ -394,8 +404,13 @@ def main():
         else:
             head = {"bound": "valu", "achieved": round(achieved, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
                     "frac": round(valu_frac, 4)}
+        # evidence from committed profiles is only as good as the kernel code it was taken on: every file carries the
+        # fingerprint of the kernel sources (tools/kernel_sha.py); anything that does not match what runs here is named
+        sha_now = kernel_sha()
+        stale = [n for n, p_ in (("traffic", traffic_p), ("sq", sq_p), ("isa_counts", isa)) if p_ and p_.get("kernel_sha16") != sha_now]
         roofline = {
             **head,
+            "kernel_sha16": sha_now, "stale": bool(stale), "stale_sources": stale,
             "traffic": traffic, "traffic_note": (traffic_src + ": " + traffic_p.get("note", "")) if traffic_p else traffic_src,
             "kernel": kernel_name, "kernel_instance": inst,
             "avg_launch_ms": round(avg_ms, 4), "launches": int(st.intersect_launches),

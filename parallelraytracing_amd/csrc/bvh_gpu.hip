@@ -303,6 +303,7 @@ __global__ void k_records(const float* __restrict__ verts, const float* __restri
 // =========================================================================================================
 #define PLOC_RADIUS_MAX 64
 static int g_ploc_radius = 24;   // search radius in Morton order (PRT_PLOC_RADIUS; tuned on C3, tools/build_compare.py)
+static int g_ploc_top = 0;       // 1: the top of the tree by full-search clustering on the device (PRT_PLOC_TOP=device)
 static float g_ploc_ci = 0.6f;   // cost of one triangle test relative to one 8-wide node visit (PRT_PLOC_CI)
 
 __device__ __forceinline__ float half_area6(const float* lo, const float* hi) {
@@ -370,6 +371,51 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ cl
         }
     }
     nn[i] = bj;
+}
+
+// The same search over ALL m clusters (the top of the tree, m <= PLOC_TOP): clusters that are far apart in Morton order see
+// each other, which the windowed search cannot offer and the upper levels need.  O(m^2) box unions = 16 M for m = 4096.
+__global__ void __launch_bounds__(256) k_ploc_nn_full(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ box,
+                                                      uint32_t* __restrict__ nn) {
+    __shared__ float s_box[256 * 6];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    float bi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < m) {
+        const float* b = box + 6 * (size_t)cl[i];
+        for (int a = 0; a < 6; ++a) bi[a] = b[a];
+    }
+    float best = 3.402823466e+38f;
+    unsigned long long best_tie = ~0ull;
+    uint32_t bj = i;
+    for (uint32_t t0 = 0; t0 < m; t0 += 256u) {  // block-uniform trip count
+        __syncthreads();
+        if (t0 + threadIdx.x < m) {
+            const float* b = box + 6 * (size_t)cl[t0 + threadIdx.x];
+            for (int a = 0; a < 6; ++a) s_box[6 * threadIdx.x + a] = b[a];
+        }
+        __syncthreads();
+        const uint32_t nt = m - t0 < 256u ? m - t0 : 256u;
+        if (i < m)
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t j = t0 + t;
+                if (j == i) continue;
+                const float* bq = &s_box[6 * t];
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = fminf(bi[a], bq[a]);
+                    hi[a] = fmaxf(bi[3 + a], bq[3 + a]);
+                }
+                const float ar = half_area6(lo, hi);
+                const uint32_t lowp = j < i ? j : i, dist = j < i ? i - j : j - i;
+                const unsigned long long tie = ((unsigned long long)dist << 33) | ((unsigned long long)(lowp & 1u) << 32) | lowp;
+                if (ar < best || (ar == best && tie < best_tie)) {
+                    best = ar;
+                    best_tie = tie;
+                    bj = j;
+                }
+            }
+    }
+    if (i < m) nn[i] = bj;
 }
 
 // flags for the scan: low word = 1 for the leader of a mutual pair (the lower position), high word = 1 for every
@@ -932,13 +978,20 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
     uint32_t* cl_in = cl_a;
     uint32_t* cl_out = cl_b;
     pass_begin.push_back(n);
-    for (uint32_t pass = 0; m > PLOC_TOP; ++pass) {
+    // g_ploc_top = 1 (PRT_PLOC_TOP=device): the passes go on below PLOC_TOP clusters with the FULL search, down to the root,
+    // and no part of the build runs on the host; 0 (default): the host's SAH sweep builds the top (2b below)
+    if (const char* e = getenv("PRT_PLOC_TOP")) g_ploc_top = !strcmp(e, "device") ? 1 : 0;
+    const uint32_t stop_at = g_ploc_top ? 1u : PLOC_TOP;
+    for (uint32_t pass = 0; m > stop_at; ++pass) {
         if (pass > 4096u) {  // every pass merges at least the globally best pair: cannot happen
             cleanup(false);
             return -4;
         }
         const dim3 g((m + 255u) / 256u), b(256);
-        hipLaunchKernelGGL(k_ploc_nn, g, b, 0, st, cl_in, m, box, nn, g_ploc_radius);
+        if (m > PLOC_TOP)
+            hipLaunchKernelGGL(k_ploc_nn, g, b, 0, st, cl_in, m, box, nn, g_ploc_radius);
+        else
+            hipLaunchKernelGGL(k_ploc_nn_full, g, b, 0, st, cl_in, m, box, nn);
         hipLaunchKernelGGL(k_ploc_flags, g, b, 0, st, nn, m, flags);
         size_t sb = scan_bytes;
         GB_TRY(rocprim::exclusive_scan(temp2, sb, flags, scan, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), st));
@@ -966,7 +1019,10 @@ int prt_gpu_bvh8_build_ploc(hipStream_t st, const float* d_verts, const float* d
     }
     // 2b. the top of the tree over the m remaining clusters: full-sweep SAH on the host, its DP rows as well
     uint32_t root_bin = 0u;
-    {
+    if (m == 1u) {  // the passes went all the way (g_ploc_top): the last cluster is the root
+        GB_TRY(hipMemcpyAsync(&root_bin, cl_in, 4, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+    } else {
         std::vector<uint32_t> h_cl(m), h_cnt(m);
         std::vector<float> h_box(6 * (size_t)m), h_cost(8 * (size_t)m);
         // (the clusters' rows are scattered over the node arrays: gathered on the device into the scan / flag buffers, which

@@ -565,12 +565,15 @@ def test_headline_frame_one_sample_bit_exact():
 
 
 # ---- device-side builder (prt_set_param("gpu_build", 1)) --------------------------------------------------------------
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, "1-top-on-device", 2])
 @pytest.mark.parametrize("ply,target", [("icosahedron.ply", 0), ("bunny.ply", 0), ("bunny.ply", 70_000)])
-def test_device_built_tree_is_valid_and_gives_the_same_hits(ply, target, mode):
-    """The 8-wide trees built on the GPU (gpu_build 1: PLOC + optimal collapse, 2: Morton octree): structurally valid (same
-    checker as the host builder's tree), and - because the closest hit does not depend on the tree - bit-exact hits
+def test_device_built_tree_is_valid_and_gives_the_same_hits(ply, target, mode, monkeypatch):
+    """The 8-wide trees built on the GPU (gpu_build 1: PLOC + optimal collapse, with the top of the tree from the host's SAH
+    sweep or, PRT_PLOC_TOP=device, from full-search clustering passes on the device; 2: Morton octree): structurally valid
+    (same checker as the host builder's tree), and - because the closest hit does not depend on the tree - bit-exact hits
     against the oracle."""
+    monkeypatch.setenv("PRT_PLOC_TOP", "device" if mode == "1-top-on-device" else "")
+    mode = 1 if mode == "1-top-on-device" else mode
     mesh = prt.scenes.refined(ply, target) if target else prt.Mesh(prt.scenes.asset(ply))
     scene = prt.scenes.mesh_scene(mesh)
     r = prt.HipWavefrontRenderer(device=0)

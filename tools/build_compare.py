@@ -14,12 +14,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
     ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--no-refit", action="store_true")
     args = ap.parse_args()
     import torch
     import parallelraytracing_amd as prt
     torch.cuda.set_device(0)
     scene, cam, W, H, _, depth = prt.scenes.config(args.config)
-    for gpu_build in (0, 1, 2):
+    for gpu_build, top in ((0, ""), (1, ""), (1, "device"), (2, "")):
+        # PRT_PLOC_TOP=device: the quality builder clusters the top of the tree on the device too (full-search passes down to
+        # the root) instead of the host's SAH sweep over the last <= 4096 clusters
+        os.environ["PRT_PLOC_TOP"] = top
         film = prt.Film(W, H)
         r = prt.HipWavefrontRenderer(device=0, max_depth=depth)
         r.set_param("gpu_build", gpu_build)
@@ -41,12 +45,14 @@ def main():
         dt = time.perf_counter() - t0
         st = r.stats()
         tr = r.measure_traversal()
-        print(f"{args.config} gpu_build={gpu_build}: build {info.build_ms:8.1f} ms (Init incl. flatten/upload {init_s:.2f} s)  "
+        print(f"{args.config} gpu_build={gpu_build}{' top on the device' if top else ''}: build {info.build_ms:8.1f} ms (Init incl. flatten/upload {init_s:.2f} s)  "
               f"nodes8 {info.n_nodes8}  depth {info.depth8}  {st.rays_total / dt / 1e6:8.1f} Mrays/s  "
               f"nodes/walked {tr.bvh_node_visits / max(1, tr.rays_traversed):.2f}  tris/walked {tr.bvh_tri_tests / max(1, tr.rays_traversed):.2f}",
               flush=True)
         del r
-    refit_rows(prt, args, scene, cam, W, H, depth)
+    os.environ["PRT_PLOC_TOP"] = ""
+    if not args.no_refit:
+        refit_rows(prt, args, scene, cam, W, H, depth)
 
 
 def refit_rows(prt, args, scene, cam, W, H, depth):

@@ -144,6 +144,9 @@ def main():
         print(f"{name}: node step {ns.get('valu')} VALU / {ns.get('total')} instructions, "
               f"triangle round {tr.get('valu')} VALU / {tr.get('total')}")
     if args.out:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from kernel_sha import kernel_sha
+        result["kernel_sha16"] = kernel_sha()
         json.dump(result, open(args.out, "w"), indent=1)
         print("wrote", args.out)
 

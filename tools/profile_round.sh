@@ -34,4 +34,8 @@ SIF=$(J "d['config']['samples_in_flight']"); SPP=$(J "d['config']['spp_per_step'
 CFG=$(J "d['config']['workload'].split(':')[0]"); JIT=$(J "d['config'].get('jitter', 0)")
 python3 $ROOT/tools/pmc_traffic.py $OUT/pass_fetch $OUT/pass_write $OUT/profiles/${TAG}_traffic.json --config $CFG --spp-per-step $SPP --sif $SIF --kernel $KERNEL --jitter $JIT --read-factor $READ_FACTOR
 python3 $ROOT/tools/pmc_sq.py $OUT $OUT/profiles/${TAG}_sq.json --config $CFG --sif $SIF --kernel $KERNEL --jitter $JIT
+# the fingerprint of the kernel sources these counters belong to, and the bench line again now that its own counter files exist
+python3 $ROOT/tools/kernel_sha.py $OUT/profiles/${TAG}_traffic.json $OUT/profiles/${TAG}_sq.json > /dev/null
+mkdir -p $ROOT/profiles && cp $OUT/profiles/${TAG}_traffic.json $OUT/profiles/${TAG}_sq.json $ROOT/profiles/
+python3 $ROOT/bench.py $ARGS 2> /dev/null | grep '^{"metric"' > $OUT/profiles/${TAG}_bench_line.json || echo "(final bench line failed; the stats pass's line is kept)"
 head -4 $OUT/profiles/${TAG}_kernel_stats.csv | cut -c1-60,300-
