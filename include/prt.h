@@ -354,6 +354,8 @@ uint32_t prt_group_size(const PrtGroup* g);
 const char* prt_group_transport(const PrtGroup* g);          /* "rccl" | "peer" | "none" (one rank) */
 PrtContext* prt_group_context(PrtGroup* g, uint32_t rank);   /* per-rank tunables / stats; owned by the group */
 int prt_group_set_scene(PrtGroup* g, const PrtSceneDesc* scene);   /* built on rank 0, cloned to the others */
+/* prt_refit_meshes on every rank (each refits the tree on its own device, in parallel; the meshes are read by all ranks). */
+int prt_group_refit_meshes(PrtGroup* g, const PrtMesh* meshes, uint32_t n_meshes);
 int prt_group_set_camera(PrtGroup* g, const PrtCameraDesc* cam);
 int prt_group_set_film(PrtGroup* g, uint32_t width, uint32_t height);
 int prt_group_film_clear(PrtGroup* g);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "prt_group_transport": (C.c_char_p, [_vp]),
     "prt_group_context": (_vp, [_vp, C.c_uint32]),
     "prt_group_set_scene": (C.c_int, [_vp, C.POINTER(PrtSceneDesc)]),
+    "prt_group_refit_meshes": (C.c_int, [_vp, C.POINTER(PrtMesh), C.c_uint32]),
     "prt_group_set_camera": (C.c_int, [_vp, C.POINTER(PrtCameraDesc)]),
     "prt_group_set_film": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "prt_group_film_clear": (C.c_int, [_vp]),

@@ -1275,6 +1275,10 @@ int prt_refit_meshes(PrtContext* c, const PrtMesh* meshes, uint32_t n_meshes) {
     c->dsc.extent = ext_all;
     c->bvh_info.refit_ms = (float)c->refit_ms;
     ++c->bvh_info.refits;
+    c->bvh_info.n_nodes = 0;      // (the binary and 4-wide trees are gone)
+    c->bvh_info.n_nodes4 = 0;
+    c->bvh_info.node_bytes = 0;
+    c->bvh_info.max_stack4 = 0;
     return PRT_OK;
 }
 

@@ -258,6 +258,12 @@ int prt_group_set_scene(PrtGroup* g, const PrtSceneDesc* scene) {
     return for_each_rank(g, [&](uint32_t r) { return r == 0 ? PRT_OK : prt_clone_scene(g->ctx[r], g->ctx[0]); });  // ... uploads in parallel
 }
 
+int prt_group_refit_meshes(PrtGroup* g, const PrtMesh* meshes, uint32_t n_meshes) {
+    if (!g || g->ctx.empty()) return PRT_ERR_INVALID;
+    g->film_current = false;
+    return for_each_rank(g, [&](uint32_t r) { return prt_refit_meshes(g->ctx[r], meshes, n_meshes); });
+}
+
 int prt_group_set_camera(PrtGroup* g, const PrtCameraDesc* cam) {
     if (!g) return PRT_ERR_INVALID;
     return for_each_rank(g, [&](uint32_t r) { return prt_set_camera(g->ctx[r], cam); }, false);

@@ -551,6 +551,12 @@ class HipWavefrontGroupRenderer:
         d = camera.desc()
         self._check(capi.lib().prt_group_set_camera(self._grp, C.byref(d)))
 
+    def Refit(self, scene: Scene):
+        """prt_group_refit_meshes: every rank refits its copy of the tree to `scene`'s deformed meshes (same topology)."""
+        d = scene.desc()
+        scene._keep = d
+        self._check(capi.lib().prt_group_refit_meshes(self._grp, d.meshes, d.n_meshes))
+
     def ProgressiveRender(self, spp: int = 1):
         self._check(capi.lib().prt_group_render(self._grp, spp, self.max_depth, self.seed, self.frame_index))
         self.frame_index += spp

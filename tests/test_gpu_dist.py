@@ -148,3 +148,32 @@ def test_cpp_cli_tiles_the_frame_over_three_ranks(tmp_path):
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     assert "1 GPU(s) [gather: none]" in outs[0][2] and "3 GPU(s) [gather: peer]" in outs[1][2]
     assert outs[0][2].split("rays")[0].split(":")[-1] == outs[1][2].split("rays")[0].split(":")[-1]  # same ray count
+
+
+def test_group_refit_on_two_contexts_matches_a_single_context():
+    """prt_group_refit_meshes: both ranks refit their copy of the tree; the assembled frame of the deformed mesh equals the
+    single-context frame (which tests/test_gpu_parity.py pins to the oracle)."""
+    import numpy as np
+    import parallelraytracing_amd as prt
+    base = prt.scenes.refined("bunny.ply", 12_000)
+    v = base.GetVertices()
+    v[:, 0] += 0.02 * np.sin(3.0 * v[:, 1])
+    moved = prt.Mesh(vertices=v, normals=base.GetNormals(), indices=base.GetIndices())
+    W, H, depth, spp = 72, 48, 4, 2
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    frames = []
+    for make in (lambda: prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=5),
+                 lambda: prt.HipWavefrontGroupRenderer([0, 0], max_depth=depth, seed=5)):
+        film = prt.Film(W, H)
+        r = make()
+        r.max_depth, r.seed = depth, 5
+        r.Init(film, prt.scenes.mesh_scene(base), cam)
+        r.ProgressiveRender(1)
+        r.Refit(prt.scenes.mesh_scene(moved))
+        r.Clear() if hasattr(r, "Clear") else film.Clear()
+        r.frame_index = 0
+        for _ in range(spp):
+            r.ProgressiveRender()
+        r.download()
+        frames.append(np.array(film.accum))
+    assert np.array_equal(frames[0], frames[1]) and frames[0].any()
