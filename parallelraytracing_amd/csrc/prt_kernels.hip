@@ -2008,6 +2008,13 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                             f3 po, pd;
                             uint32_t pixel, sample;
                             primary_ray(pr, pr.pid[qi], po, pd, pixel, sample);
+                            // every primary ray starts at the camera, a kernel argument: left visible, the compiler hoists
+                            // everything that depends on the origin alone (o +- pad, |o|_1, ...) out of the persistent loop
+                            // and keeps it in VGPRs for the kernel's life, 8 of which it then spills (36 B of scratch, 8
+                            // scratch loads per refill); opaque, the same values cost 8 VALU instructions per refill
+#ifndef PRT_NO_OPAQUE_ORIGIN  // (A/B builds)
+                            asm volatile("" : "+v"(po.x), "+v"(po.y), "+v"(po.z));
+#endif
                             O = make_float4(po.x, po.y, po.z, 0.f);
                             D = make_float4(pd.x, pd.y, pd.z, 0.f);
                         } else {
