@@ -421,7 +421,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             if (compact && d == 0) {
                 if (c->tune.primary_hit) {  // (timed with the shade stage)
                     if ((rc = begin_event(c, 2, &ep))) return rc;
-                    prt_launch_primary_hit(c->stream, c->dsc, primary, in.hit, c->d_pix);
+                    prt_launch_primary_hit(c->stream, c->dsc, primary, in.hit, c->d_pix, c->d_counts);
                     if ((rc = end_event(c, &ep))) return rc;
                 } else {  // A/B: "no record" for every pixel (hit id 0xFFFFFFFF never equals a hit k_shade looks up)
                     HIPCHECK(c, hipMemsetAsync(c->d_pix + 2 * (size_t)c->tm.n_pix_local, 0xFF, 2 * (size_t)c->tm.n_pix_local * sizeof(float4), c->stream));
@@ -434,7 +434,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             n_rays_known = c->h_counts[64 * (size_t)d] + c->h_counts[64 * (size_t)d + 32];
             if (n_rays_known == 0u) break;  // every path has ended: the later bounces have nothing to do
         }
-        if (c->d_shade_div) prt_launch_shade_divstats(c->stream, c->dsc, in, c->d_counts, d, n_paths, c->d_shade_div);
+        if (c->d_shade_div) prt_launch_shade_divstats(c->stream, c->dsc, in, c->d_counts, d, n_paths, c->d_shade_div, (compact && d == 0) ? &primary : nullptr);
         if ((rc = begin_event(c, 2, &ep))) return rc;
         prt_launch_shade(c->stream, c->dsc, in, out, c->d_rad, c->d_counts, c->d_work, d, max_depth, n_paths, fuse, c->sampling,
                          n_rays_known, (compact && d == 0) ? &primary : nullptr);

@@ -115,7 +115,8 @@ struct PrtRayBuf {
 // (0) are functions of the path id alone, so k_raygen stores 12 B per path (path id, the analytic scan's hit id and
 // distance) instead of 56 B plus ONE 16-B record per pixel (direction, pixel index), and the first bounce's traversal
 // and k_shade rebuild the ray from those (C3: 372 M stored primary rays per 256-spp batch = 16 GB less written by
-// k_raygen and 12 GB less read by the first k_shade).  Every primary ray is still traced on its own.  pid aliases the
+// k_raygen and 12 GB less read by the first k_shade; round 3: the analytic scan's hit of a primary ray is per pixel too, so a
+// path's slot holds its id only).  Every primary ray is still traced on its own.  pid aliases the
 // `t` array of the ray buffer (first 4 bytes per slot).
 struct PrtPrimary {
     const uint32_t* pid;  // path id per ray slot
@@ -166,10 +167,11 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
                       uint32_t fuse_max, const PrtSampling& sp, uint32_t n_rays_known, const PrtPrimary* primary = nullptr);
 // diagnostic: per-wave material mix of what k_shade of bounce `iter` is about to shade (16 words per bounce in `out`)
 void prt_launch_shade_divstats(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* counts, uint32_t iter,
-                               uint32_t cap, unsigned long long* out);
+                               uint32_t cap, unsigned long long* out, const PrtPrimary* primary = nullptr);
 // compact primary rays: per-pixel surface interaction of the primary hit (records 2n.. and 3n.. of `pix`), between the
 // first traversal and the first k_shade of a batch
-void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix);
+void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix,
+                            const uint32_t* counts);
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats,
                            const float4* pix_end = nullptr);

@@ -353,8 +353,10 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                         rd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(path_seed(pixel, first_sample + sl, seed)));
                         rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
                     }
-                    hit[slot] = id0;
-                    hd2[slot] = d2_0;
+                    if (!COMPACT) {  // (compact: the analytic scan's result is the pixel's, in its end record)
+                        hit[slot] = id0;
+                        hd2[slot] = d2_0;
+                    }
                 }
             }
         } else {
@@ -397,8 +399,10 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
                         rd[slot] = make_float4(Dp.x, Dp.y, Dp.z, __uint_as_float(path_seed(pixp, first_sample + s0 + lane, seed)));
                         rt[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
                     }
-                    hit[slot] = idp;
-                    hd2[slot] = d2p;
+                    if (!COMPACT) {
+                        hit[slot] = idp;
+                        hd2[slot] = d2p;
+                    }
                 }
             }
         }
@@ -407,9 +411,11 @@ __global__ void __launch_bounds__(PRODUCER_BLOCK) k_raygen(DevScene sc, DevCamer
             if (COMPACT) {
                 // whether the pixel's paths end with their primary ray, and with what, is the same for all its samples: one
                 // record per pixel (w = 0xFFFFFFFE: they go on, look in rad[]) instead of S copies in rad[]
-                // (x of a "they go on" record: the ray slot of the pixel's first stored sample, for k_primary_hit)
+                // (a "they go on" record: x = the ray slot of the pixel's first stored sample, for k_primary_hit; y, z = the
+                // analytic scan's closest hit and its distance^2, the same for every sample of the pixel: the paths' slots
+                // carry the path id only, 4 B instead of 12)
                 if (in_range && blockIdx.y == 0)
-                    pix[tm.n_pix_local + pl] = stored ? make_float4(__uint_as_float(first_slot), 0.f, 0.f, __uint_as_float(0xFFFFFFFEu)) : L0;
+                    pix[tm.n_pix_local + pl] = stored ? make_float4(__uint_as_float(first_slot), __uint_as_float(id0), d2_0, __uint_as_float(0xFFFFFFFEu)) : L0;
             } else if (in_range && !stored) {
                 // the path ended with its primary ray (sky / light seen directly), or there is none
                 for (uint32_t sl = s0; sl < s1; ++sl) rad[sl * tm.n_pix_local + pl] = L0;
@@ -2001,13 +2007,17 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 const uint32_t qi_seq = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (idle && qi_seq < cur_end) {
                     const uint32_t qi = (!PRIM && tune.perm) ? tune.perm[qi_seq] : qi_seq;  // (sort_rays: a measurement aid)
-                    const uint32_t hid = hit[qi];
+                    uint32_t hid = PRIM ? HIT_MISS : hit[qi];
                     if (hid != HIT_DEAD) {
                         float4 O, D;
+                        float hd2_0 = 0.0f;
                         if (PRIM) {
                             f3 po, pd;
-                            uint32_t pixel, sample;
-                            primary_ray(pr, pr.pid[qi], po, pd, pixel, sample);
+                            uint32_t pixel, sample, lp;
+                            primary_ray(pr, pr.pid[qi], po, pd, pixel, sample, &lp);
+                            const float4 E = pr.pix[pr.n_pix_local + lp];  // the pixel's analytic hit (k_raygen)
+                            hid = __float_as_uint(E.y);
+                            hd2_0 = E.z;
                             // every primary ray starts at the camera, a kernel argument: left visible, the compiler hoists
                             // everything that depends on the origin alone (o +- pad, |o|_1, ...) out of the persistent loop
                             // and keeps it in VGPRs for the kernel's life, 8 of which it then spills (36 B of scratch, 8
@@ -2039,7 +2049,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         octinv4 = (7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u))) * 0x01010101u;
                         best.id = hid;
                         best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
-                        best.d2 = hd2[qi];
+                        best.d2 = PRIM ? hd2_0 : hd2[qi];
                         tlimit = limit_from_d2(best.d2, pad);
                         if (LEAN) {
                             s_lray[0 * 256 + tid] = o.x; s_lray[1 * 256 + tid] = o.y; s_lray[2 * 256 + tid] = o.z;
@@ -2331,11 +2341,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     float4 pre_a = make_float4(0.f, 0.f, 0.f, 0.f), pre_b = pre_a;
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
-        const uint32_t id = hit[src];
+        uint32_t id = (PRIM && k >= nA) ? HIT_MISS : hit[src];
         if (PRIM) {
             pid = pr.pid[src];
             uint32_t pixel, sample, lp;
             primary_ray(pr, pid, o, d, pixel, sample, &lp);
+            // a back-side primary ray was never walked: its closest hit is the analytic scan's, kept per pixel (k_raygen)
+            if (k >= nA) id = __float_as_uint(pr.pix[pr.n_pix_local + lp].y);
             rng = path_seed(pixel, pr.first_sample + sample, pr.seed);
             depth = 0u;
             thr = mk3(1.f, 1.f, 1.f);
@@ -2376,13 +2388,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
 // of one pixel.  This kernel rebuilds it per PIXEL from the hit id of the pixel's first stored sample, and k_shade<PRIM>
 // uses the record for every sample whose own hit id equals the record's (otherwise it computes the hit itself).
 __global__ void __launch_bounds__(256) k_primary_hit(DevScene sc, PrtPrimary pr, const uint32_t* __restrict__ hit,
-                                                     float4* __restrict__ pix) {
+                                                     float4* __restrict__ pix, const uint32_t* __restrict__ counts) {
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
     if (pl >= pr.n_pix_local) return;
     const float4 E = pix[pr.n_pix_local + pl];
     float4 a = make_float4(0.f, 0.f, 0.f, __uint_as_float(HIT_DEAD)), b = make_float4(0.f, 0.f, 0.f, 0.f);  // no record
     if (__float_as_uint(E.w) == 0xFFFFFFFEu) {  // the pixel's paths were stored
-        const uint32_t id = hit[__float_as_uint(E.x)];
+        // front-side slots (below the front count) were walked: their hit is the traversal's; back-side paths keep the
+        // analytic scan's hit of the pixel's record
+        const uint32_t first = __float_as_uint(E.x);
+        const uint32_t id = first < CNT_A(counts, 0) ? hit[first] : __float_as_uint(E.y);
         if (id != HIT_MISS && id != HIT_DEAD) {
             const float4 P = pix[pl];
             WorldHit w;
@@ -2405,7 +2420,7 @@ __global__ void __launch_bounds__(256) k_primary_hit(DevScene sc, PrtPrimary pr,
 // holds, so [14] / [15] is the factor by which material divergence multiplies the scatter work.
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade_divstats(DevScene sc, const uint32_t* __restrict__ hit,
                                                                  const uint32_t* __restrict__ counts, uint32_t iter, uint32_t cap,
-                                                                 unsigned long long* __restrict__ out) {
+                                                                 unsigned long long* __restrict__ out, PrtPrimary pr, int compact) {
     const uint32_t nA = CNT_A(counts, iter), nB = CNT_B(counts, iter);
     const uint32_t count = nA + nB;
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;
@@ -2413,7 +2428,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade_divstats(DevScene sc, con
     uint32_t type = 5u;  // no ray
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);
-        const uint32_t id = hit[src];
+        uint32_t id;
+        if (compact && k >= nA) {  // compact primary rays: a back-side path's hit is its pixel's analytic one (k_shade<PRIM>)
+            f3 o_, d_;
+            uint32_t pixel, sample, lp;
+            primary_ray(pr, pr.pid[src], o_, d_, pixel, sample, &lp);
+            id = __float_as_uint(pr.pix[pr.n_pix_local + lp].y);
+        } else {
+            id = hit[src];
+        }
         type = 0u;
         if (id != HIT_MISS && id != HIT_DEAD) {
             uint32_t m;
@@ -2930,12 +2953,14 @@ void prt_launch_shade(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, c
 }
 
 void prt_launch_shade_divstats(hipStream_t st, const DevScene& sc, const PrtRayBuf& in, const uint32_t* counts, uint32_t iter,
-                               uint32_t cap, unsigned long long* out) {
-    hipLaunchKernelGGL(k_shade_divstats, dim3((cap + SHADE_BLOCK - 1u) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, sc, in.hit, counts, iter, cap, out);
+                               uint32_t cap, unsigned long long* out, const PrtPrimary* primary) {
+    hipLaunchKernelGGL(k_shade_divstats, dim3((cap + SHADE_BLOCK - 1u) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, sc, in.hit, counts, iter, cap, out,
+                       primary ? *primary : PrtPrimary{}, primary ? 1 : 0);
 }
 
-void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix) {
-    hipLaunchKernelGGL(k_primary_hit, dim3(blocks_for(pr.n_pix_local)), dim3(256), 0, st, sc, pr, hit, pix);
+void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary& pr, const uint32_t* hit, float4* pix,
+                            const uint32_t* counts) {
+    hipLaunchKernelGGL(k_primary_hit, dim3(blocks_for(pr.n_pix_local)), dim3(256), 0, st, sc, pr, hit, pix, counts);
 }
 
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
