@@ -37,5 +37,8 @@ python3 $ROOT/tools/pmc_sq.py $OUT $OUT/profiles/${TAG}_sq.json --config $CFG --
 # the fingerprint of the kernel sources these counters belong to, and the bench line again now that its own counter files exist
 python3 $ROOT/tools/kernel_sha.py $OUT/profiles/${TAG}_traffic.json $OUT/profiles/${TAG}_sq.json > /dev/null
 mkdir -p $ROOT/profiles && cp $OUT/profiles/${TAG}_traffic.json $OUT/profiles/${TAG}_sq.json $ROOT/profiles/
+# (the loops' static instruction counts of exactly this kernel code as well: the line takes its per-trip VALU counts from them)
+ROUND=${TAG%%_*}
+python3 $ROOT/tools/isa_count.py --out $ROOT/profiles/${ROUND}_isa_counts.json > /dev/null 2>&1 && cp $ROOT/profiles/${ROUND}_isa_counts.json $OUT/profiles/
 python3 $ROOT/bench.py $ARGS 2> /dev/null | grep '^{"metric"' > $OUT/profiles/${TAG}_bench_line.json || echo "(final bench line failed; the stats pass's line is kept)"
 head -4 $OUT/profiles/${TAG}_kernel_stats.csv | cut -c1-60,300-
