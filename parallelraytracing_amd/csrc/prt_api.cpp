@@ -28,6 +28,7 @@ namespace {
 
 constexpr float kPadCoeff = 1.0f / 262144.0f;  // 2^-18, see traverse() in prt_kernels.hip
 constexpr uint32_t kMaxLeaf = 3;  // the compressed 8-wide node encodes at most 3 triangles per leaf (bvh.h)
+constexpr size_t kRayStatWords = (size_t)PRT_RAY_STAT_SLOTS * PRT_MAX_DEPTH;
 constexpr uint32_t kTravStatsWords = 16 + PRT_TIMELINE_WORDS * (PRT_MAX_DEPTH + 1);  // counters + one launch timeline per bounce
 constexpr uint32_t kMaxStack = 63;  // LDS stack entries per lane: 31 (5 blocks/CU) or 63 (2 blocks/CU)
 
@@ -91,7 +92,10 @@ struct PrtContext {
     PrtRayBuf rb[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
     float4* d_rad = nullptr;
     uint32_t* d_counts = nullptr;             // (PRT_MAX_DEPTH + 2) x PRT_CNT_STRIDE: front/back ray counts per bounce
-    unsigned long long* d_ray_stats = nullptr;  // PRT_MAX_DEPTH
+    unsigned long long* d_ray_stats = nullptr;  // [2][PRT_RAY_STAT_SLOTS][PRT_MAX_DEPTH]: the context's counters, then a scratch set for measurement runs
+    unsigned long long* ray_stats_target = nullptr;  // the set k_accumulate adds to (d_ray_stats, or its scratch half during a measurement)
+    bool pix_records_blank = false;  // d_pix's primary-hit records all say "no record" (batches of one sample)
+    uint32_t* h_flag = nullptr;  // pinned: the traversal kernels' error flags (d_work[256]) as of the last prt_synchronize
     unsigned long long* d_trav_stats = nullptr; // 3
 
     // ---- scratch for the function-level entry points ----
@@ -205,10 +209,11 @@ int ensure_path_state(PrtContext* c, uint64_t n_paths) {
 int ensure_counters(PrtContext* c) {
     if (c->d_counts) return PRT_OK;
     HIPCHECK(c, hipMalloc((void**)&c->d_counts, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_ray_stats, kRayStatWords * 2 * sizeof(unsigned long long)));
+    c->ray_stats_target = c->d_ray_stats;
     HIPCHECK(c, hipMalloc((void**)&c->d_trav_stats, kTravStatsWords * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_counts, 0, (PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE * sizeof(uint32_t)));
-    HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    HIPCHECK(c, hipMemset(c->d_ray_stats, 0, kRayStatWords * 2 * sizeof(unsigned long long)));
     HIPCHECK(c, hipMemset(c->d_trav_stats, 0, kTravStatsWords * sizeof(unsigned long long)));
     // [0..255] chunk cursors (one 128-B line per XCD), [256] watchdog flag, [512] overflow count, [513..] overflow list
     HIPCHECK(c, hipMalloc((void**)&c->d_work, (513 + (1u << 20)) * sizeof(uint32_t)));
@@ -253,6 +258,17 @@ void free_scene(PrtContext* c) {
 }
 
 // timing helpers ----------------------------------------------------------------------------------
+// the per-depth ray counters of one set: the sum over its slots (prt_kernels.h PRT_RAY_STAT_SLOTS)
+int read_ray_stats(PrtContext* c, const unsigned long long* d_set, unsigned long long (&out)[PRT_MAX_DEPTH]) {
+    std::vector<unsigned long long> h(kRayStatWords);
+    HIPCHECK(c, hipMemcpy(h.data(), d_set, kRayStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int d = 0; d < PRT_MAX_DEPTH; ++d) {
+        out[d] = 0;
+        for (size_t sl = 0; sl < PRT_RAY_STAT_SLOTS; ++sl) out[d] += h[sl * PRT_MAX_DEPTH + (size_t)d];
+    }
+    return PRT_OK;
+}
+
 int begin_event(PrtContext* c, int kind, EventPair* ep) {
     if (!c->timing) return PRT_OK;
     if (!c->event_pool.empty()) {
@@ -351,7 +367,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         if ((rc = end_event(c, &ep))) return rc;
         ++c->stats.intersect_launches;
         if ((rc = begin_event(c, 3, &ep))) return rc;
-        prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats, nullptr);
+        prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->ray_stats_target, nullptr);
         if ((rc = end_event(c, &ep))) return rc;
         if (accumulate) c->stats.samples += S_cur;
         HIPCHECK(c, hipGetLastError());
@@ -368,6 +384,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
         c->pix_entries = 0;
         HIPCHECK(c, hipMalloc((void**)&c->d_pix, 4 * (size_t)c->tm.n_pix_local * sizeof(float4)));
         c->pix_entries = c->tm.n_pix_local;
+        c->pix_records_blank = false;
     }
     const PrtPrimary primary{(const uint32_t*)c->rb[0].t, c->d_pix, {c->cam.pos.x, c->cam.pos.y, c->cam.pos.z}, c->tm.n_pix_local,
                              1.0f / (float)c->tm.n_pix_local, first_sample, seed};
@@ -419,12 +436,15 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
             if ((rc = end_event(c, &ep))) return rc;
             ++c->stats.intersect_launches;
             if (compact && d == 0) {
-                if (c->tune.primary_hit) {  // (timed with the shade stage)
+                // (a batch of ONE sample has nothing to share: k_shade rebuilds the hit itself, one launch less)
+                if (c->tune.primary_hit && S_cur > 1u) {  // (timed with the shade stage)
                     if ((rc = begin_event(c, 2, &ep))) return rc;
                     prt_launch_primary_hit(c->stream, c->dsc, primary, in.hit, c->d_pix, c->d_counts);
                     if ((rc = end_event(c, &ep))) return rc;
-                } else {  // A/B: "no record" for every pixel (hit id 0xFFFFFFFF never equals a hit k_shade looks up)
+                    c->pix_records_blank = false;
+                } else if (!c->pix_records_blank) {  // "no record" for every pixel (hit id 0xFFFFFFFF never equals a hit k_shade looks up); stays so until k_primary_hit runs again
                     HIPCHECK(c, hipMemsetAsync(c->d_pix + 2 * (size_t)c->tm.n_pix_local, 0xFF, 2 * (size_t)c->tm.n_pix_local * sizeof(float4), c->stream));
+                    c->pix_records_blank = true;
                 }
             }
         }
@@ -444,7 +464,7 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     // film += the batch's samples (unless this is a measurement run) and per-depth ray counts from the paths' last
     // segment indices
     if ((rc = begin_event(c, 3, &ep))) return rc;
-    prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->d_ray_stats,
+    prt_launch_accumulate(c->stream, c->d_rad, c->d_film_local, c->tm, S_cur, max_depth, accumulate, c->ray_stats_target,
                           compact ? c->d_pix + c->tm.n_pix_local : nullptr);
     if ((rc = end_event(c, &ep))) return rc;
     if (accumulate) c->stats.samples += S_cur;
@@ -647,6 +667,7 @@ void prt_destroy(PrtContext* c) {
         free_dev(c->d_film_local);
         free_dev(c->d_counts);
         free_dev(c->d_ray_stats);
+        if (c->h_flag) (void)hipHostFree(c->h_flag);
         free_dev(c->d_trav_stats);
         if (c->h_counts) {
             (void)hipHostFree(c->h_counts);
@@ -1322,6 +1343,7 @@ int prt_set_film(PrtContext* c, uint32_t width, uint32_t height, uint32_t rank, 
     }
     c->valid_local = valid;
     c->has_film = true;
+    c->pix_records_blank = false;  // (the records' place in d_pix depends on the pixel count)
     if (!c->has_device) return PRT_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -1373,10 +1395,16 @@ int prt_render_async(PrtContext* c, uint32_t spp, uint32_t max_depth, uint32_t s
 int prt_synchronize(PrtContext* c) {
     int rc = need_device(c);
     if (rc) return rc;
+    // (the flag's copy is enqueued behind the kernels and ONE wait covers both: a blocking copy after the wait was a second
+    // host round trip, ~30 us of a 0.9 ms one-sample call)
+    if (c->d_work && !c->h_flag) {
+        HIPCHECK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
+        *c->h_flag = 0u;
+    }
+    if (c->d_work) HIPCHECK(c, hipMemcpyAsync(c->h_flag, c->d_work + 256, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_work) {  // watchdog flag of the persistent traversal kernel
-        uint32_t w = 0;
-        HIPCHECK(c, hipMemcpy(&w, c->d_work + 256, sizeof(w), hipMemcpyDeviceToHost));
+        const uint32_t w = *c->h_flag;
         if (w) {
             HIPCHECK(c, hipMemset(c->d_work, 0, 2052));
             return fail(c, PRT_ERR_HIP, w & 2u ? "traversal stack-overflow list full" : "traversal watchdog tripped: a wave exceeded its iteration cap");
@@ -1595,7 +1623,7 @@ int prt_get_stats(PrtContext* c, PrtStats* out) {
     PrtStats s = c->stats;
     if (c->d_ray_stats) {
         unsigned long long h[PRT_MAX_DEPTH];
-        HIPCHECK(c, hipMemcpy(h, c->d_ray_stats, sizeof(h), hipMemcpyDeviceToHost));
+        if ((rc = read_ray_stats(c, c->d_ray_stats, h))) return rc;
         s.rays_total = 0;
         for (int d = 0; d < PRT_MAX_DEPTH; ++d) {
             s.rays_per_depth[d] = h[d];
@@ -1613,7 +1641,7 @@ int prt_reset_stats(PrtContext* c) {
     if ((rc = drain_events(c))) return rc;
     memset(&c->stats, 0, sizeof(c->stats));
     c->dead_paths = 0;
-    if (c->d_ray_stats) HIPCHECK(c, hipMemset(c->d_ray_stats, 0, PRT_MAX_DEPTH * sizeof(unsigned long long)));
+    if (c->d_ray_stats) HIPCHECK(c, hipMemset(c->d_ray_stats, 0, kRayStatWords * sizeof(unsigned long long)));
     return PRT_OK;
 }
 
@@ -1630,18 +1658,19 @@ int prt_measure_traversal(PrtContext* c, uint32_t max_depth, uint32_t seed, uint
     const bool timing = c->timing;
     const uint64_t launches = c->stats.intersect_launches;
     c->timing = false;
-    // the per-depth ray counters are cumulative: take this run's share as a difference and put the old values back
-    unsigned long long before[PRT_MAX_DEPTH], after[PRT_MAX_DEPTH];
-    HIPCHECK(c, hipMemcpy(before, c->d_ray_stats, sizeof(before), hipMemcpyDeviceToHost));
+    // the per-depth ray counters are cumulative: this run counts into the scratch set
+    unsigned long long before[PRT_MAX_DEPTH] = {}, after[PRT_MAX_DEPTH];
+    HIPCHECK(c, hipMemset(c->d_ray_stats + kRayStatWords, 0, kRayStatWords * sizeof(unsigned long long)));
+    c->ray_stats_target = c->d_ray_stats + kRayStatWords;
     // measure_spp (prt_set_param) samples in one batch: the counters scale, the per-phase cycle split becomes that of a
     // loaded kernel
     rc = run_batch(c, (uint32_t)std::max(1, c->measure_spp), max_depth, seed, sample, false, c->d_trav_stats);
+    c->ray_stats_target = c->d_ray_stats;
     c->timing = timing;
     c->stats.intersect_launches = launches;
     if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    HIPCHECK(c, hipMemcpy(after, c->d_ray_stats, sizeof(after), hipMemcpyDeviceToHost));
-    HIPCHECK(c, hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice));
+    if ((rc = read_ray_stats(c, c->d_ray_stats + kRayStatWords, after))) return rc;
     unsigned long long t[kTravStatsWords];
     std::vector<uint32_t> cnt((size_t)(PRT_MAX_DEPTH + 2) * PRT_CNT_STRIDE);
     HIPCHECK(c, hipMemcpy(t, c->d_trav_stats, sizeof(t), hipMemcpyDeviceToHost));
@@ -1688,10 +1717,9 @@ int prt_measure_shade_divergence(PrtContext* c, uint32_t max_depth, uint32_t see
     unsigned long long* buf = nullptr;
     HIPCHECK(c, hipMalloc((void**)&buf, bytes));
     hipError_t e = hipMemsetAsync(buf, 0, bytes, c->stream);
-    unsigned long long before[PRT_MAX_DEPTH];
-    if (e == hipSuccess) e = hipMemcpy(before, c->d_ray_stats, sizeof(before), hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
         c->d_shade_div = buf;
+        c->ray_stats_target = c->d_ray_stats + kRayStatWords;  // (the run's rays are not the context's)
         const bool timing = c->timing;
         const uint64_t launches = c->stats.intersect_launches;
         c->timing = false;
@@ -1699,8 +1727,8 @@ int prt_measure_shade_divergence(PrtContext* c, uint32_t max_depth, uint32_t see
         c->timing = timing;
         c->stats.intersect_launches = launches;
         c->d_shade_div = nullptr;
+        c->ray_stats_target = c->d_ray_stats;
         if (!rc) e = hipStreamSynchronize(c->stream);
-        if (!rc && e == hipSuccess) e = hipMemcpy(c->d_ray_stats, before, sizeof(before), hipMemcpyHostToDevice);
         if (!rc && e == hipSuccess) e = hipMemcpy(out, buf, 16 * (size_t)max_depth * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     }
     (void)hipFree(buf);

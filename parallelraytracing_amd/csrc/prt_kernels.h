@@ -102,6 +102,9 @@ struct PrtTravTuning {
 // [4] sum over waves of (end - exhausted) = wave time spent draining, [5] sum over waves of (end - start), [6] waves,
 // [7] node steps of the longest ray
 #define PRT_TIMELINE_WORDS 8
+// k_accumulate's per-depth ray counters exist PRT_RAY_STAT_SLOTS times ([slot][PRT_MAX_DEPTH], block b adds to slot
+// b mod SLOTS); the host sums the slots when it reads them
+#define PRT_RAY_STAT_SLOTS 256u
 
 struct PrtRayBuf {
     float4* o;      // origin.xyz, path id

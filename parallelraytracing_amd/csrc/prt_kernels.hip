@@ -1679,7 +1679,11 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     const uint32_t gran_per_chunk = tune.chunk >> 6;
     const uint32_t n_gran = (count + 63u) >> 6;
     const uint32_t n_wv = gridDim.x * 4u;
-    const uint32_t tail_want = n_wv * tune.tail;
+    // A launch with fewer than 8 granules per resident wave has no bulk at all: a quarter of its waves would start with a
+    // four-granule chunk and still be on it when the rest of the buffer is gone (one-sample calls at 1080p, 2 M + 1.2 M
+    // rays for 5,120 waves: traversal 764 -> 642 us per call; from ~12 granules per wave on chunks win again, and
+    // single granules throughout cost 20-30 % at 4-64 samples per call: one atomic per 64 rays; tools/probe log in TUNING.md)
+    const uint32_t tail_want = n_gran < n_wv * 8u ? n_gran : n_wv * tune.tail;
     const uint32_t n_bulk = (n_gran - (tail_want < n_gran ? tail_want : n_gran)) / gran_per_chunk;  // chunks
     const uint32_t n_grabs = n_bulk + (n_gran - n_bulk * gran_per_chunk);
     bool first_grab = true;  // wave-uniform
@@ -2539,7 +2543,9 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
     if (threadIdx.x < max_depth) {
         unsigned long long n = 0;
         for (uint32_t e = threadIdx.x; e < max_depth; ++e) n += s_ends[e];
-        if (n) atomicAdd(&ray_stats[threadIdx.x], n);
+        // (PRT_RAY_STAT_SLOTS copies of the counters, summed by the host when it reads them: a single word would execute only
+        // ~87 of these atomics per microsecond, a floor of 23 us for 2,048 blocks, half of a one-sample k_accumulate)
+        if (n) atomicAdd(&ray_stats[(blockIdx.x & (PRT_RAY_STAT_SLOTS - 1u)) * PRT_MAX_DEPTH + threadIdx.x], n);
     }
 }
 
@@ -2966,7 +2972,7 @@ void prt_launch_primary_hit(hipStream_t st, const DevScene& sc, const PrtPrimary
 void prt_launch_accumulate(hipStream_t st, const float4* rad, float4* film_local, const PrtTileMap& tm, uint32_t S,
                            uint32_t max_depth, bool update_film, unsigned long long* ray_stats, const float4* pix_end) {
     const uint32_t nb = blocks_for(tm.n_pix_local ? tm.n_pix_local : 1);
-    hipLaunchKernelGGL(k_accumulate, dim3(nb < 2048u ? nb : 2048u), dim3(256), 0, st, rad, film_local, tm, S, max_depth,
+    hipLaunchKernelGGL(k_accumulate, dim3(nb < 8192u ? nb : 8192u), dim3(256), 0, st, rad, film_local, tm, S, max_depth,
                        update_film ? 1 : 0, ray_stats, pix_end);
 }
 

@@ -12,6 +12,9 @@ for cfg in a.config.split(","):
     film = prt.Film(W, H)
     r = prt.HipWavefrontRenderer(device=0, max_depth=depth, seed=0)
     r.Init(film, scene, cam)
+    for kv in filter(None, os.environ.get("PRT_PARAMS", "").split(",")):  # A/B: PRT_PARAMS=name=value,...
+        k, v = kv.split("=")
+        r.set_param(k, int(v))
     for _ in range(5):
         r.ProgressiveRender()
     r.reset_stats()
