@@ -125,6 +125,8 @@ struct PrtContext {
     size_t sort_entries = 0, sort_temp = 0;
     uint32_t* h_counts = nullptr;  // pinned: the front / back ray counts of each bounce as the host learns them
     hipEvent_t ev_counts[PRT_MAX_DEPTH + 2] = {};
+    hipEvent_t ev_prod[PRT_MAX_DEPTH + 2] = {};  // "the producer of bounce d's counts is done" (render stream -> count stream)
+    hipStream_t count_stream = nullptr;          // the counts' copies to the host run beside the render stream, not in it
     uint32_t* d_work = nullptr;   // chunk cursor of the persistent traversal kernel
     float4* d_pix = nullptr;      // compact primary rays: one record per local pixel (PrtPrimary)
     uint32_t pix_entries = 0;
@@ -343,11 +345,18 @@ int run_batch(PrtContext* c, uint32_t S_cur, uint32_t max_depth, uint32_t seed, 
     if (exact && !c->h_counts) {
         HIPCHECK(c, hipHostMalloc((void**)&c->h_counts, (PRT_MAX_DEPTH + 2) * 64 * sizeof(uint32_t), hipHostMallocDefault));
         for (hipEvent_t& e : c->ev_counts) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : c->ev_prod) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(c, hipStreamCreateWithFlags(&c->count_stream, hipStreamNonBlocking));
     }
     auto read_back = [&](uint32_t d) -> hipError_t {  // counts of bounce d: words 0 (front) and 32 (back) of its stride
-        hipError_t e = hipMemcpyAsync(c->h_counts + 64 * (size_t)d, c->d_counts + (size_t)d * PRT_CNT_STRIDE, 33 * sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, c->stream);
-        return e != hipSuccess ? e : hipEventRecord(c->ev_counts[d], c->stream);
+        // (on a stream of its own behind an event: in the render stream the 4-us copy kernel and the gaps around it were
+        // 10-20 us per bounce, 1 % of a step of a rank of eight)
+        hipError_t e = hipEventRecord(c->ev_prod[d], c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->count_stream, c->ev_prod[d], 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->h_counts + 64 * (size_t)d, c->d_counts + (size_t)d * PRT_CNT_STRIDE, 33 * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->count_stream);
+        return e != hipSuccess ? e : hipEventRecord(c->ev_counts[d], c->count_stream);
     };
     EventPair ep{};
     // Small batches (the reference's contract: ONE sample per ProgressiveRender call, cpu/renderer.cpp:49) can run as one
@@ -672,6 +681,8 @@ void prt_destroy(PrtContext* c) {
         if (c->h_counts) {
             (void)hipHostFree(c->h_counts);
             for (hipEvent_t& e : c->ev_counts) (void)hipEventDestroy(e);
+            for (hipEvent_t& e : c->ev_prod) (void)hipEventDestroy(e);
+            if (c->count_stream) (void)hipStreamDestroy(c->count_stream);
         }
         free_dev(c->d_work);
         free_dev(c->d_pix);

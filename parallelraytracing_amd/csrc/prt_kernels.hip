@@ -970,6 +970,15 @@ PRT_DEV uint32_t wave_scan_add(uint32_t x) {
     x += PRT_DPP(x, 0x143, 0xC);  // row_bcast:31 -> rows 2, 3
     return x;
 }
+PRT_DEV uint32_t wave_scan_or(uint32_t x) {
+    x |= PRT_DPP(x, 0x111, 0xF);
+    x |= PRT_DPP(x, 0x112, 0xF);
+    x |= PRT_DPP(x, 0x114, 0xF);
+    x |= PRT_DPP(x, 0x118, 0xF);
+    x |= PRT_DPP(x, 0x142, 0xA);
+    x |= PRT_DPP(x, 0x143, 0xC);
+    return x;
+}
 PRT_DEV uint32_t wave_scan_max(uint32_t x) {
     uint32_t t;
     t = PRT_DPP(x, 0x111, 0xF); x = x > t ? x : t;
@@ -1677,12 +1686,14 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // over 8 GPUs.  Small launches consist of single granules only.  A wave's FIRST grab needs no atomic (grab number =
     // its index in the grid; 5120 simultaneous atomics on one word take ~60 us); the cursor counts the grabs after it.
     const uint32_t gran_per_chunk = tune.chunk >> 6;
-    const uint32_t n_gran = (count + 63u) >> 6;
     const uint32_t n_wv = gridDim.x * 4u;
+    const uint32_t n_gran = (count + 63u) >> 6;
     // A launch with fewer than 8 granules per resident wave has no bulk at all: a quarter of its waves would start with a
     // four-granule chunk and still be on it when the rest of the buffer is gone (one-sample calls at 1080p, 2 M + 1.2 M
     // rays for 5,120 waves: traversal 764 -> 642 us per call; from ~12 granules per wave on chunks win again, and
-    // single granules throughout cost 20-30 % at 4-64 samples per call: one atomic per 64 rays; tools/probe log in TUNING.md)
+    // single granules throughout cost 20-30 % at 4-64 samples per call: one atomic per 64 rays; TUNING.md.  Thinner
+    // granules for launches smaller than the grid, 8-32 rays in every wave instead of 64 in a few, change nothing: such a
+    // launch lasts as long as its longest ray, whatever shares the wave with it)
     const uint32_t tail_want = n_gran < n_wv * 8u ? n_gran : n_wv * tune.tail;
     const uint32_t n_bulk = (n_gran - (tail_want < n_gran ? tail_want : n_gran)) / gran_per_chunk;  // chunks
     const uint32_t n_grabs = n_bulk + (n_gran - n_bulk * gran_per_chunk);
@@ -1736,9 +1747,16 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             break;
         }
         unsigned long long helped = 0ull;  // STEAL: root lanes that have helpers at work (wave-uniform)
-        if (STEAL && exhausted) {
-            for (unsigned long long hm = __ballot(k >= 0xFFFFFF00u && k != 0xFFFFFFFFu); hm; hm &= hm - 1ull)
-                helped |= 1ull << ((uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(hm)) & 63u);
+        if (STEAL && exhausted) {  // (all lanes are active here; two OR scans instead of one readlane per helper: a draining
+            // wave has up to 63 of them and pays this in every outer iteration)
+            const bool helper = k >= 0xFFFFFF00u && k != 0xFFFFFFFFu;
+            if (__ballot(helper) != 0ull) {
+                const uint32_t r = k & 63u;
+                const uint32_t lo = wave_scan_or((helper && r < 32u) ? 1u << r : 0u);
+                const uint32_t hi = wave_scan_or((helper && r >= 32u) ? 1u << (r - 32u) : 0u);
+                helped = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+            }
         }
         // a lane is released only when nothing of its ray is left in the queue (the testers read the owner's ray)
         if (k != 0xFFFFFFFFu && !pending && !(INST && (in_blas || ipm != 0u))) {
@@ -1911,7 +1929,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     if (cur == cur_end) {  // grab the next chunk / granule of path ids (as the ray hand-out above)
                         uint32_t c = blockIdx.x * 4u + wv;
                         if (!first_grab) {
-                            if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
+                            if (n_grabs <= n_wv) c = n_grabs;  // (every grab went out with the waves' first ones)
+                            else if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
                             c = (uint32_t)__shfl((int)c, 0, 64);
                         }
                         first_grab = false;
@@ -1993,7 +2012,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
             if (cur == cur_end) {  // grab the next chunk / granule
                 uint32_t c = blockIdx.x * 4u + wv;
                 if (!first_grab) {
-                    if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
+                    if (n_grabs <= n_wv) c = n_grabs;  // (every grab went out with the waves' first ones)
+                    else if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
                     c = (uint32_t)__shfl((int)c, 0, 64);
                 }
                 first_grab = false;

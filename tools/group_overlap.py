@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3"); ap.add_argument("--spp", type=int, default=64); ap.add_argument("--ks", default="1,2,4")
 ap.add_argument("--reps", type=int, default=4); ap.add_argument("--jitter", type=int, default=0)
+ap.add_argument("--params", default="", help="prt_set_param pairs for every context with K > 1, e.g. grid_blocks=512")
 args = ap.parse_args()
 import parallelraytracing_amd as prt
 scene, cam, W, H, _, depth = prt.scenes.config(args.config)
@@ -15,6 +16,9 @@ for k in [int(x) for x in args.ks.split(",")]:
     r.Init(film, scene, cam)
     if args.jitter:
         r.set_sampling(jitter=1)
+    for kv in filter(None, args.params.split(",")) if k > 1 else []:
+        name, v = kv.split("=")
+        r.set_param(name, int(v))
     r.set_samples_in_flight(min(args.spp, 256))
     r.ProgressiveRender(args.spp)
     ts = []
