@@ -728,6 +728,32 @@ def test_batching_and_samples_in_flight_do_not_change_the_image():
         assert np.array_equal(f.accum, ref_f.accum) and np.array_equal(f.weights, ref_f.weights), (S, calls)
 
 
+def test_switching_between_one_sample_and_multi_sample_calls_on_a_mesh_scene():
+    """A batch of ONE sample skips k_primary_hit (its per-pixel records are blanked once and stay blank), a larger batch
+    writes them again: any order of call sizes gives the frame and the ray counts of the oracle, with exact grids (the
+    count read-backs on their own stream) as well."""
+    mesh = prt.scenes.refined("bunny.ply", 30_000)
+    scene = prt.scenes.mesh_scene(mesh)
+    W, H, depth, seed = 96, 54, 5, 3
+    cam = prt.Camera(position=(2.0, 1.5, 3.0), width=W, height=H)
+    osc = util.oracle_scene(scene)
+    acc, wts, rays = osc.render(cam.desc(), W, H, spp=10, max_depth=depth, seed=seed, iterative=True, use_bvh=True, n_threads=8)
+    for exact in (0, 2):
+        r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=seed, cam=cam)
+        r.set_param("exact_grids", exact)
+        r.set_samples_in_flight(8)
+        for calls in (1, 5, 1, 1, 2):
+            r.ProgressiveRender(calls)
+        r.download()
+        assert np.array_equal(film.accum, acc) and np.array_equal(film.weights, wts), exact
+        st = r.stats()
+        assert st.rays_total == rays and st.rays_per_depth[0] == 10 * W * H, exact
+        # a measurement run counts into its own set of counters: the context's stay what they were
+        r.measure_traversal(sample=3)
+        st2 = r.stats()
+        assert st2.rays_total == rays and list(st2.rays_per_depth) == list(st.rays_per_depth)
+
+
 def test_partitioned_render_equals_single_render():
     """world_size 1 vs 3 ranks (three contexts on the one GPU): same film bits after gather + resolve."""
     import torch
