@@ -513,9 +513,10 @@ def main():
     # ---- secondary block (N = 1): the other single-GPU configs, jittered C3, the reference's default scene ----
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
-        secondary = {"note": "same pipeline, timed in this run with inputs resident; reduced sample counts (spp_per_step x steps), "
-                             "64 samples in flight; the headline stays C3 without jitter"}
-        secondary["C3_jitter"] = time_config(prt, torch, "C3", local_rank, 64, 3, sampling={"jitter": 1})
+        secondary = {"note": "same pipeline, timed in this run with inputs resident; reduced sample counts (spp_per_step x steps; "
+                             "C3_jitter: the headline's own 256 samples per step), spp_per_step samples in flight; the headline "
+                             "stays C3 without jitter"}
+        secondary["C3_jitter"] = time_config(prt, torch, "C3", local_rank, 256, 3, sampling={"jitter": 1})
         secondary["C2"] = time_config(prt, torch, "C2", local_rank, 64, 3)
         secondary["C5"] = time_config(prt, torch, "C5", local_rank, 64, 2)
         secondary["C5I"] = time_config(prt, torch, "C5I", local_rank, 64, 2)
