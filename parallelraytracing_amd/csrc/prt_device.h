@@ -11,6 +11,27 @@
 
 #define PRT_DEV __device__ __forceinline__
 
+// Streamed-once data (ray records, path results) is LOADED with the non-temporal hint, so that it does not push the tree out
+// of the L2s / the Infinity Cache (-DPRT_NO_NT: plain, for A/B builds).  Measured (TUNING.md): loads C3 +-0, C5 +1.3 %;
+// the same hint on the STORES made the first k_shade of a batch 39 % slower, on the vertex-normal gathers of k_shade 8 %
+// slower, on the traversal's triangle gathers 24 % slower (they are re-used from L1): those stay plain.
+typedef float prt_v4f __attribute__((ext_vector_type(4)));
+#ifndef PRT_NO_NT
+PRT_DEV float4 ld_stream(const float4* p) {
+    const prt_v4f v = __builtin_nontemporal_load((const prt_v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PRT_DEV uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+PRT_DEV float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+#else
+PRT_DEV float4 ld_stream(const float4* p) { return *p; }
+PRT_DEV uint32_t ld_stream(const uint32_t* p) { return *p; }
+PRT_DEV float ld_stream(const float* p) { return *p; }
+#endif
+PRT_DEV void st_stream(float4* p, float4 v) { *p = v; }
+PRT_DEV void st_stream(uint32_t* p, uint32_t v) { *p = v; }
+PRT_DEV void st_stream(float* p, float v) { *p = v; }
+
 PRT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 PRT_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 PRT_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }

@@ -221,14 +221,14 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
 #pragma unroll
     for (int it = 0; it <= BUDGET; ++it) {
         if (id == HIT_MISS) {  // the miss branch of IntersectClosestKernel, renderer.cu:263-271
-            *rad_slot = path_result(thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]), sp.clamp, depth);
+            st_stream(rad_slot, path_result(thr * mk3(sc.sky[0], sc.sky[1], sc.sky[2]), sp.clamp, depth));
             return 0;
         }
         if (it == BUDGET) {  // only reached with an analytic id (the ray was classified "cannot hit a triangle")
             const uint32_t m = sc.prims[id].material;
             if (sc.mat_type[m] == 4u) {  // emissive: never scatters (material.h:119-122): the path stops here
                 const float4 e = sc.mat_rgbs[m];
-                *rad_slot = path_result(thr * mk3(e.x, e.y, e.z), sp.clamp, depth);
+                st_stream(rad_slot, path_result(thr * mk3(e.x, e.y, e.z), sp.clamp, depth));
                 return 0;
             }
             id0 = id;
@@ -253,7 +253,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             scattered = material_scatter(type, rgbs, d, w.pos, w.normal, w.front, rng, atten, emitted, so, sd);
         }
         if (!scattered) {
-            *rad_slot = path_result(thr * emitted, sp.clamp, depth);
+            st_stream(rad_slot, path_result(thr * emitted, sp.clamp, depth));
             return 0;
         }
         thr = thr * atten;
@@ -265,7 +265,7 @@ PRT_DEV int advance_path(const DevScene& sc, uint32_t id, f3& o, f3& d, f3& thr,
             p = p > 1.0f ? 1.0f : p;
             p = p < 0.05f ? 0.05f : p;
             if (!(rnd01(rng) < p)) {
-                *rad_slot = path_result(mk3(0.f, 0.f, 0.f), 0.0f, depth);
+                st_stream(rad_slot, path_result(mk3(0.f, 0.f, 0.f), 0.0f, depth));
                 return 0;
             }
             thr = mk3(thr.x / p, thr.y / p, thr.z / p);
@@ -1781,7 +1781,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 } else if (STEAL && k >= 0xFFFFFF00u) {  // a helper (k = 0xFFFFFF00 | root lane): its subtree is done
                     k = 0xFFFFFFFFu;
                 } else if (!STEAL || ((helped >> lane) & 1ull) == 0ull) {
-                    hit[k] = LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id;
+                    st_stream(&hit[k], LEAN ? ((volatile uint32_t*)s_slot)[tid] : best.id);
 #ifdef PRT_PROBE_REBOUND  // diagnostic build: leave the final distance where the next launch takes its initial bound from
                     ((float*)hd2)[k] = LEAN ? __uint_as_float((uint32_t)(((volatile unsigned long long*)s_key)[tid] >> 32)) : best.d2;
 #endif
@@ -2031,14 +2031,14 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 const uint32_t qi_seq = cur + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (idle && qi_seq < cur_end) {
                     const uint32_t qi = (!PRIM && tune.perm) ? tune.perm[qi_seq] : qi_seq;  // (sort_rays: a measurement aid)
-                    uint32_t hid = PRIM ? HIT_MISS : hit[qi];
+                    uint32_t hid = PRIM ? HIT_MISS : ld_stream(&hit[qi]);
                     if (hid != HIT_DEAD) {
                         float4 O, D;
                         float hd2_0 = 0.0f;
                         if (PRIM) {
                             f3 po, pd;
                             uint32_t pixel, sample, lp;
-                            primary_ray(pr, pr.pid[qi], po, pd, pixel, sample, &lp);
+                            primary_ray(pr, ld_stream(&pr.pid[qi]), po, pd, pixel, sample, &lp);
                             const float4 E = pr.pix[pr.n_pix_local + lp];  // the pixel's analytic hit (k_raygen)
                             hid = __float_as_uint(E.y);
                             hd2_0 = E.z;
@@ -2052,8 +2052,8 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                             O = make_float4(po.x, po.y, po.z, 0.f);
                             D = make_float4(pd.x, pd.y, pd.z, 0.f);
                         } else {
-                            O = ro[qi];
-                            D = rd[qi];
+                            O = ld_stream(&ro[qi]);
+                            D = ld_stream(&rd[qi]);
                         }
                         o = mk3(O.x, O.y, O.z);
                         ld = normalize3(mk3(D.x, D.y, D.z));  // TransformNormal(identity, d), primitive.cpp:30
@@ -2073,7 +2073,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         octinv4 = (7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u))) * 0x01010101u;
                         best.id = hid;
                         best.prim = hid;  // analytic index, or 0xFFFFFFFF for a miss
-                        best.d2 = PRIM ? hd2_0 : hd2[qi];
+                        best.d2 = PRIM ? hd2_0 : ld_stream(&hd2[qi]);
                         tlimit = limit_from_d2(best.d2, pad);
                         if (LEAN) {
                             s_lray[0 * 256 + tid] = o.x; s_lray[1 * 256 + tid] = o.y; s_lray[2 * 256 + tid] = o.z;
@@ -2365,9 +2365,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     float4 pre_a = make_float4(0.f, 0.f, 0.f, 0.f), pre_b = pre_a;
     if (k < count) {
         const uint32_t src = k < nA ? k : cap - 1u - (k - nA);  // front part, then back part
-        uint32_t id = (PRIM && k >= nA) ? HIT_MISS : hit[src];
+        uint32_t id = (PRIM && k >= nA) ? HIT_MISS : ld_stream(&hit[src]);
         if (PRIM) {
-            pid = pr.pid[src];
+            pid = ld_stream(&pr.pid[src]);
             uint32_t pixel, sample, lp;
             primary_ray(pr, pid, o, d, pixel, sample, &lp);
             // a back-side primary ray was never walked: its closest hit is the analytic scan's, kept per pixel (k_raygen)
@@ -2378,9 +2378,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
             pre_a = pr.pix[2u * pr.n_pix_local + lp];
             pre_b = pr.pix[3u * pr.n_pix_local + lp];
         } else {
-            const float4 O = ro[src];
-            const float4 D = rd[src];
-            const float4 T = rt[src];
+            const float4 O = ld_stream(&ro[src]);
+            const float4 D = ld_stream(&rd[src]);
+            const float4 T = ld_stream(&rt[src]);
             pid = __float_as_uint(O.w);
             rng = __float_as_uint(D.w);
             depth = __float_as_uint(T.w);  // segment index of this ray (paths advance at different rates, see advance_path)
@@ -2397,11 +2397,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, const float4
     const uint32_t slot = block_alloc2<SHADE_BLOCK>(front, back, false, &CNT_A(counts, iter + 1u), &CNT_B(counts, iter + 1u),
                                                     &CNT_C(counts, iter + 1u), cap);
     if (slot != 0xFFFFFFFFu) {
-        no[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
-        nd[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
-        nt[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(depth));
-        nhit[slot] = id0;
-        nhd2[slot] = d2_0;
+        st_stream(&no[slot], make_float4(o.x, o.y, o.z, __uint_as_float(pid)));
+        st_stream(&nd[slot], make_float4(d.x, d.y, d.z, __uint_as_float(rng)));
+        st_stream(&nt[slot], make_float4(thr.x, thr.y, thr.z, __uint_as_float(depth)));
+        st_stream(&nhit[slot], id0);
+        st_stream(&nhd2[slot], d2_0);
     }
 }
 
@@ -2539,7 +2539,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const float4* __restrict__ r
         float4 r[8];
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j)
-            r[j] = (valid && !ended && s0 + j < S) ? rad[(size_t)(s0 + j) * tm.n_pix_local + pl] : E;
+            r[j] = (valid && !ended && s0 + j < S) ? ld_stream(&rad[(size_t)(s0 + j) * tm.n_pix_local + pl]) : E;
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j) {
             if (s0 + j >= S) break;
