@@ -520,6 +520,27 @@ def test_image_parity_instanced_scene_vs_oracle():
     assert st.bvh_node_visits > 0 and st.bvh_tri_tests > 0 and st.max_stack_used <= 12
 
 
+def test_traversal_error_flag_reaches_the_caller_and_clears():
+    """The two-level walk has no fallback for a full stack: the kernel raises its error flag, prt_synchronize (whose copy of
+    the flag to pinned memory is enqueued before its one stream wait) reports it, clears it, and the context stays usable."""
+    mesh = prt.scenes.refined("bunny.ply", 12_000)
+    scene = _instanced_scene(mesh, with_world_mesh=True)
+    W, H, depth = 96, 54, 4
+    cam = prt.Camera(position=(6.0, 4.0, 9.0), width=W, height=H)
+    r, film, _ = make_renderer(scene, W, H, max_depth=depth, seed=2, cam=cam)
+    r.set_param("stack_cap", 1)
+    with pytest.raises(prt.PrtError, match="overflow"):
+        r.ProgressiveRender(2)
+    r.set_param("stack_cap", 0)
+    film.Clear()
+    r.reset_stats()
+    r.ProgressiveRender(2)  # no stale flag
+    r.download()
+    acc, wts, rays = util.oracle_scene(scene).render(cam.desc(), W, H, spp=2, max_depth=depth, seed=2, iterative=True,
+                                                     use_bvh=True, n_threads=8)
+    assert np.array_equal(film.accum, acc) and r.stats().rays_total == rays
+
+
 def test_placed_copies_next_to_many_analytic_primitives():
     """Both acceleration structures at once: 109 analytic primitives (primitive BVH in the producers) + placed copies of
     a mesh (two-level tree in the traversal kernel), jittered and with roulette: image bit-exact vs the oracle."""
