@@ -83,7 +83,7 @@ struct PrtTravTuning {
     uint32_t exit_max;     // leave the node loop when at most this many lanes still search for a leaf (0xFFFFFFFF = per instance: 32 two-level, 16 otherwise)
     uint32_t xcd_affinity; // 4-wide / binary kernels, A/B: 1 = each XCD drains its own eighth of the ray buffer first (L2 locality), then steals
     uint32_t wide;         // 2: walk the compressed 8-wide tree (default), 1: the 4-wide tree, 0: the binary tree
-    uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles
+    uint32_t tri_min;      // 8-wide kernel: start a triangle phase once this many lane-steps have queued triangles (0 = per tree: 12 for one-level trees with one node per 128-B line, 24 otherwise)
     uint32_t fuse;         // k_shade: 1 = shade one analytic-only segment in place per call (default), 0 = store every ray
     uint32_t stack_cap;    // test hook: the 8-wide kernel treats its stack as this many entries (0 = all of them)
     uint32_t stack_lds;    // selects the kernel instance (stack entries in LDS / waves per SIMD), see prt_launch_traverse

@@ -95,7 +95,7 @@ def test_scene_validation_errors():
         r.set_sampling(clamp=-1.0)
     r.set_sampling(jitter=1, rr_depth=3, clamp=4.0)
     r.set_sampling()
-    for name, bad_value in (("wide", 3), ("fuse", 2), ("gpu_build", 5), ("tri_min", 0), ("chunk", 100), ("nonsense", 1)):
+    for name, bad_value in (("wide", 3), ("fuse", 2), ("gpu_build", 5), ("tri_min", -1), ("chunk", 100), ("nonsense", 1)):
         with pytest.raises(prt.PrtError, match="unknown parameter or bad value"):
             r.set_param(name, bad_value)
     # an instance that points at a mesh that is not there
