@@ -1,8 +1,3 @@
-    // tri_min "auto" (0, the context's default): a triangle phase starts after 24 queueing lane-steps, but after 12 on one-level
-    // trees far beyond the caches (one node per 128-B line: C5 +1.7 %; 16: +0.8 to +1.9 %), whose walks gain more from an earlier
-    // culling bound than a phase's fixed part costs.  On trees the caches hold 12 / 16 cost 0.5-2 % (C2, C3), and the two-level
-    // instance at its exit_max of 32 is best at 24 too (16: -1.5 %).  tools/sweep.py, TUNING.md
-    if (tune.tri_min == 0u) tune.tri_min = (t8_kind(sc, tune_in) != T8_INST12_4 && sc.node_stride == 8u) ? 12u : 24u;
 // prt_kernels.hip — hand-written HIP kernels of the wavefront path tracer for gfx950 (MI355X).
 //
 // Pipeline per sample batch (one batch = `S` samples per local pixel in flight):
@@ -2797,11 +2792,11 @@ void prt_launch_traverse(hipStream_t st, const DevScene& sc, const PrtRayBuf& in
     // every other instance at <= 16
     PrtTravTuning tune = tune_in;
     if (tune.exit_max == 0xFFFFFFFFu) tune.exit_max = t8_kind(sc, tune_in) == T8_INST12_4 ? 32u : 16u;
-    // tri_min "auto" (0, the context's default): a triangle phase starts after 24 queueing lane-steps on trees the caches hold
-    // (C2 / C3 / C4: 12 or 16 cost 0.5-2 %), after 16 on the big ones (one node per 128-B line: C5 +1.7 %) and in the two-level
-    // instance (C5I +1.7 %), whose walks gain more from tighter culling bounds than a phase's fixed part costs
-    // (tools/sweep.py, TUNING.md)
-    if (tune.tri_min == 0u) tune.tri_min = (t8_kind(sc, tune_in) == T8_INST12_4 || sc.node_stride == 8u) ? 16u : 24u;
+    // tri_min "auto" (0, the context's default): a triangle phase starts after 24 queueing lane-steps, but after 12 on one-level
+    // trees far beyond the caches (one node per 128-B line: C5 +1.7 %; 16: +0.8 to +1.9 %), whose walks gain more from an earlier
+    // culling bound than a phase's fixed part costs.  On trees the caches hold 12 / 16 cost 0.5-2 % (C2, C3), and the two-level
+    // instance at its exit_max of 32 is best at 24 too (16: -1.5 %).  tools/sweep.py, TUNING.md
+    if (tune.tri_min == 0u) tune.tri_min = (t8_kind(sc, tune_in) != T8_INST12_4 && sc.node_stride == 8u) ? 12u : 24u;
 #ifdef PRT_PROBE_REBOUND
     // diagnostic build (tools/bounce_stats.py --rebound): the instrumented launch is preceded by a plain one that leaves
     // every ray's FINAL hit distance as its initial culling bound, so the instrumented walk's visit counts are those of a
