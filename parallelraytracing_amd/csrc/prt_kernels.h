@@ -94,6 +94,9 @@ struct PrtTravTuning {
     const uint32_t* perm;  // measurement aid (sort_rays): the 8-wide kernel takes ray perm[i] where it would take ray i (nullptr = identity)
     uint32_t path_kernel;  // host: 0 = off (default); 1 = a batch of ONE sample with at most path_max paths runs as one launch of the path instance of the 8-wide kernel (below); 2 = any batch of at most path_max paths
     uint32_t path_max;
+    uint32_t big;          // 8-wide kernel: launches with >= big_min granules per resident wave hand out the front of their bulk `big` chunks per grab (1 = off)
+    uint32_t big_min;      // (granules per resident wave)
+    uint32_t big_keep;     // granules per resident wave at the end of the bulk that stay ordinary chunks
     uint32_t primary_hit;  // host: with compact primary rays, rebuild the primary hit's surface interaction once per pixel (k_primary_hit); 0 = per sample in k_shade (A/B)
 };
 

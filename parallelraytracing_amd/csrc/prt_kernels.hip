@@ -1696,7 +1696,15 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // launch lasts as long as its longest ray, whatever shares the wave with it)
     const uint32_t tail_want = n_gran < n_wv * 8u ? n_gran : n_wv * tune.tail;
     const uint32_t n_bulk = (n_gran - (tail_want < n_gran ? tail_want : n_gran)) / gran_per_chunk;  // chunks
-    const uint32_t n_grabs = n_bulk + (n_gran - n_bulk * gran_per_chunk);
+    // Big launches (>= tune.big_min = 96 granules per resident wave; e.g. the first two bounces of a 256-sample batch at 1080p,
+    // 190 M and 318 M rays) hand out the FRONT of the bulk in chunks of tune.big chunks each: at 256 rays per grab the 318 M-ray launch
+    // asks the cursor 1.24 M times in 13.7 ms = 90 grabs per us, which is all a counter word executes (~87 / us,
+    // tools/atomic_rate.hip); any launch that runs at > 20 G rays/s is there.  The last 32 granules per wave stay ordinary chunks,
+    // so the end of the launch is balanced as before.  C3 +1.7 % at 256 samples per batch, +1.2 % at 64, +1 % at 32; C4 +2.3 %.
+    const uint32_t big = (tune.big > 1u && n_gran >= n_wv * tune.big_min) ? tune.big : 1u;
+    const uint32_t mid_keep = n_wv * tune.big_keep / gran_per_chunk;  // ordinary chunks kept for the end of the bulk (32 granules per wave)
+    const uint32_t n_big = big > 1u ? (n_bulk - (mid_keep < n_bulk ? mid_keep : n_bulk)) / big : 0u;  // grabs of `big` chunks each
+    const uint32_t n_grabs = n_big + (n_bulk - n_big * big) + (n_gran - n_bulk * gran_per_chunk);
     bool first_grab = true;  // wave-uniform
     const uint32_t my_xcd = xcc_id();
     const uint32_t tid = threadIdx.x;
@@ -1945,8 +1953,10 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                         if (c >= n_grabs) {
                             exhausted = true;
                         } else {
-                            const uint32_t g0 = c < n_bulk ? c * gran_per_chunk : n_bulk * gran_per_chunk + (c - n_bulk);
-                            const uint32_t g1 = c < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
+                            // grab c: [0, n_big) big grabs, then the ordinary chunks, then the single granules
+                            const uint32_t cb = c - n_big + n_big * big;  // (c >= n_big) the grab's index counted in ordinary chunks
+                            const uint32_t g0 = c < n_big ? c * big * gran_per_chunk : cb < n_bulk ? cb * gran_per_chunk : n_bulk * gran_per_chunk + (cb - n_bulk);
+                            const uint32_t g1 = c < n_big ? g0 + big * gran_per_chunk : cb < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
                             cur = g0 << 6;
                             cur_end = (g1 << 6) < count ? (g1 << 6) : count;
                         }
@@ -2029,8 +2039,10 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                     exhausted = true;
                     if (STATS) t_exh = __builtin_amdgcn_s_memrealtime();
                 } else {
-                    const uint32_t g0 = c < n_bulk ? c * gran_per_chunk : n_bulk * gran_per_chunk + (c - n_bulk);
-                    const uint32_t g1 = c < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
+                    // grab c: [0, n_big) big grabs, then the ordinary chunks, then the single granules
+                    const uint32_t cb = c - n_big + n_big * big;  // (c >= n_big) the grab's index counted in ordinary chunks
+                    const uint32_t g0 = c < n_big ? c * big * gran_per_chunk : cb < n_bulk ? cb * gran_per_chunk : n_bulk * gran_per_chunk + (cb - n_bulk);
+                    const uint32_t g1 = c < n_big ? g0 + big * gran_per_chunk : cb < n_bulk ? g0 + gran_per_chunk : g0 + 1u;
                     cur = g0 << 6;
                     cur_end = (g1 << 6) < count ? (g1 << 6) : count;
                 }

@@ -100,6 +100,11 @@ def run_case(case, seed):
     if rng.random() < 0.2 and kind in ("world",):
         params["stack_cap"] = int(rng.integers(2, 6))  # forces the overflow list (host-built trees only: needs the 4-wide tree)
         params.pop("gpu_build", None)
+    if rng.random() < 0.25:  # the big-grab tier of the ray hand-out, forced onto small launches
+        params["big"] = int(rng.choice([2, 3, 5]))
+        params["big_min"] = 1
+        params["big_keep"] = int(rng.choice([0, 1, 4]))
+        params["chunk"] = int(rng.choice([64, 128, 256]))
     if rng.random() < 0.2:
         params["refill_min"] = int(rng.choice([1, 8, 32, 64]))
     if rng.random() < 0.2:

@@ -178,6 +178,28 @@ def test_closest_hit_small_launches_subtree_stealing_bit_exact():
             assert util.hits_equal(r.closest_hit(pos[:n], dirs[:n]), want[:n]) == [], (steal, n)
 
 
+def test_closest_hit_every_tier_of_the_ray_hand_out_bit_exact():
+    """The traversal kernel hands its ray buffer out in three tiers: big grabs of `big` chunks at the front of big
+    launches, ordinary chunks, single 64-ray granules at the end (or throughout, for small launches).  A small resident grid
+    and forced thresholds put all three tiers, odd sizes and the tier boundaries into one 200 k-ray launch: every ray must
+    come out exactly once, with the oracle's hit."""
+    mesh = prt.scenes.refined("bunny.ply", 30_000)
+    scene = prt.scenes.mesh_scene(mesh)
+    r, _, _ = make_renderer(scene, 16, 16)
+    rng = np.random.default_rng(5)
+    o, d = util.random_rays(rng, 200_003, center=(0, 0.3, 0), radius=4.0, spread=1.5)
+    want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=True, n_threads=8)
+    assert (want["prim"] >= 2).sum() > 20_000
+    for params in ({"grid_blocks": 8, "big": 3, "big_min": 1, "big_keep": 4, "chunk": 128},
+                   {"grid_blocks": 8, "big": 2, "big_min": 1, "big_keep": 0, "chunk": 256, "tail": 3},
+                   {"grid_blocks": 24, "big": 5, "big_min": 8, "big_keep": 1, "chunk": 64, "tail": 0},
+                   {"grid_blocks": 1024, "big": 2, "big_min": 96, "big_keep": 32, "chunk": 256, "tail": 1}):
+        for k, v in params.items():
+            r.set_param(k, v)
+        for n in (200_003, 65_537):
+            assert util.hits_equal(r.closest_hit(o[:n], d[:n]), want[:n]) == [], (params, n)
+
+
 def test_scatter_bit_exact_all_materials():
     scene = prt.Scene("DEFAULT")
     scene.AddMetal((0.9, 0.8, 0.7), 0.0)
