@@ -118,7 +118,7 @@ struct PrtContext {
     PrtSampling sampling{0u, 0u, 0.0f};
     // grid 256 CUs x 4 blocks, 256-ray chunks, refill at 16 idle lanes, leave the node loop at <= 16 walkers, triangle
     // phase after 24 queueing lane-steps, 8-wide tree (all measured best on C3, tools/sweep.py); XCD affinity off
-    PrtTravTuning tune{1024u, 256u, 16u, 0xFFFFFFFFu /* exit_max: auto */, 0u, 2u, 0u /* tri_min: auto */, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 0u, 2500000u, 2u /* big */, 96u /* big_min */, 32u /* big_keep */, 1u};
+    PrtTravTuning tune{1024u, 256u, 16u, 0xFFFFFFFFu /* exit_max: auto */, 0u, 2u, 0u /* tri_min: auto */, 0u, 0u, 0u, 1u, 8u, 1u, 0u, nullptr, 0u, 2500000u, 2u /* big */, 8u /* static_small */, 96u /* big_min */, 32u /* big_keep */, 1u};
     unsigned long long* d_shade_div = nullptr;  // diagnostic (prt_measure_shade_divergence): 16 words per bounce, or null
     uint32_t sort_rays = 0;       // measurement aid: 1 / 2 = bounces >= 1 (and jittered bounce 0) walk their rays in sorted order
     uint32_t* d_sort = nullptr;   // keys, keys2, idx, idx2 (n_paths each) + rocPRIM's temporary storage
@@ -1825,6 +1825,7 @@ int prt_set_param(PrtContext* c, const char* name, int value) {
     else if (n == "pad_log2" && value >= 8 && value <= 22) c->pad_coeff = std::ldexp(1.0f, -value);
     else if (n == "tail" && value >= 0 && value <= 64) c->tune.tail = (uint32_t)value;
     else if (n == "big" && value >= 1 && value <= 16) c->tune.big = (uint32_t)value;
+    else if (n == "static_small" && value >= 0 && value <= 4096) c->tune.static_small = (uint32_t)value;
     else if (n == "big_min" && value >= 1 && value <= 100000) c->tune.big_min = (uint32_t)value;
     else if (n == "big_keep" && value >= 0 && value <= 1024) c->tune.big_keep = (uint32_t)value;
     else if (n == "stack_cap" && value >= 0 && value <= 64) c->tune.stack_cap = (uint32_t)value;

@@ -95,6 +95,7 @@ struct PrtTravTuning {
     uint32_t path_kernel;  // host: 0 = off (default); 1 = a batch of ONE sample with at most path_max paths runs as one launch of the path instance of the 8-wide kernel (below); 2 = any batch of at most path_max paths
     uint32_t path_max;
     uint32_t big;          // 8-wide kernel: launches with >= big_min granules per resident wave hand out the front of their bulk `big` chunks per grab (1 = off)
+    uint32_t static_small; // 8-wide kernel: launches of single granules only (< 8 per resident wave) deal them to the waves round-robin instead of through the cursor
     uint32_t big_min;      // (granules per resident wave)
     uint32_t big_keep;     // granules per resident wave at the end of the bulk that stay ordinary chunks
     uint32_t primary_hit;  // host: with compact primary rays, rebuild the primary hit's surface interaction once per pixel (k_primary_hit); 0 = per sample in k_shade (A/B)

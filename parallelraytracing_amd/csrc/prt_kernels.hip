@@ -1694,7 +1694,7 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     // single granules throughout cost 20-30 % at 4-64 samples per call: one atomic per 64 rays; TUNING.md.  Thinner
     // granules for launches smaller than the grid, 8-32 rays in every wave instead of 64 in a few, change nothing: such a
     // launch lasts as long as its longest ray, whatever shares the wave with it)
-    const uint32_t tail_want = n_gran < n_wv * 8u ? n_gran : n_wv * tune.tail;
+    const uint32_t tail_want = (n_gran < n_wv * 8u || n_gran < n_wv * tune.static_small) ? n_gran : n_wv * tune.tail;
     const uint32_t n_bulk = (n_gran - (tail_want < n_gran ? tail_want : n_gran)) / gran_per_chunk;  // chunks
     // Big launches (>= tune.big_min = 96 granules per resident wave; e.g. the first two bounces of a 256-sample batch at 1080p,
     // 190 M and 318 M rays) hand out the FRONT of the bulk in chunks of tune.big chunks each: at 256 rays per grab the 318 M-ray launch
@@ -1706,6 +1706,13 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
     const uint32_t n_big = big > 1u ? (n_bulk - (mid_keep < n_bulk ? mid_keep : n_bulk)) / big : 0u;  // grabs of `big` chunks each
     const uint32_t n_grabs = n_big + (n_bulk - n_big * big) + (n_gran - n_bulk * gran_per_chunk);
     bool first_grab = true;  // wave-uniform
+    uint32_t my_grabs = 0u;  // wave-uniform
+    // Launches of single granules only (fewer than tune.static_small = 8 per resident wave) do not use the cursor at all: wave w
+    // takes granules w, w + n_wv, w + 2 n_wv, ...  A grab through the cursor stalls the whole wave for the atomic's round trip,
+    // and a one-sample call's two big launches made 32 k + 19 k of them in ~170 us each (one-sample calls 1,350 -> 1,510 per
+    // second, 2 / 4 samples per call +11 / +6 %, 8-32 samples +1 to +3 % through their late bounces; with a threshold of 32 and
+    // more the dealt-out launches of 16+ samples lose 2-5 % to imbalance; TUNING.md)
+    const bool static_small = n_gran < n_wv * tune.static_small;
     const uint32_t my_xcd = xcc_id();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = lane_id();
@@ -2031,10 +2038,12 @@ __global__ void __launch_bounds__(256, WAVES) k_traverse8_persistent(DevScene sc
                 uint32_t c = blockIdx.x * 4u + wv;
                 if (!first_grab) {
                     if (n_grabs <= n_wv) c = n_grabs;  // (every grab went out with the waves' first ones)
+                    else if (static_small) c += my_grabs * n_wv;  // (a small launch: wave w takes granules w, w + n_wv, ...: no cursor)
                     else if (lane == 0) c = atomicAdd(work, 1u) + n_wv;
                     c = (uint32_t)__shfl((int)c, 0, 64);
                 }
                 first_grab = false;
+                ++my_grabs;
                 if (c >= n_grabs) {
                     exhausted = true;
                     if (STATS) t_exh = __builtin_amdgcn_s_memrealtime();

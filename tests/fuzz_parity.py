@@ -105,6 +105,8 @@ def run_case(case, seed):
         params["big_min"] = 1
         params["big_keep"] = int(rng.choice([0, 1, 4]))
         params["chunk"] = int(rng.choice([64, 128, 256]))
+    if rng.random() < 0.3:
+        params["static_small"] = int(rng.choice([0, 2, 64]))  # granules dealt round-robin / through the cursor
     if rng.random() < 0.2:
         params["refill_min"] = int(rng.choice([1, 8, 32, 64]))
     if rng.random() < 0.2:

@@ -190,7 +190,9 @@ def test_closest_hit_every_tier_of_the_ray_hand_out_bit_exact():
     o, d = util.random_rays(rng, 200_003, center=(0, 0.3, 0), radius=4.0, spread=1.5)
     want = util.oracle_scene(scene).closest_hit(o, d, use_bvh=True, n_threads=8)
     assert (want["prim"] >= 2).sum() > 20_000
-    for params in ({"grid_blocks": 8, "big": 3, "big_min": 1, "big_keep": 4, "chunk": 128},
+    for params in ({"grid_blocks": 8, "big": 3, "big_min": 1, "big_keep": 4, "chunk": 128, "static_small": 0},
+                   {"grid_blocks": 64, "static_small": 4096},  # every granule dealt round-robin, no cursor
+                   {"grid_blocks": 8, "static_small": 8},
                    {"grid_blocks": 8, "big": 2, "big_min": 1, "big_keep": 0, "chunk": 256, "tail": 3},
                    {"grid_blocks": 24, "big": 5, "big_min": 8, "big_keep": 1, "chunk": 64, "tail": 0},
                    {"grid_blocks": 1024, "big": 2, "big_min": 96, "big_keep": 32, "chunk": 256, "tail": 1}):

@@ -10,7 +10,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-DEFAULTS = {"variant": 0, "grid_blocks": 1024, "chunk": 256, "refill_min": 16, "exit_max": 16, "xcd_affinity": 0, "wide": 2, "stack_lds": 0, "tri_min": 0, "fuse": 0, "exact_grids": 1, "steal": 8, "tail": 1, "big": 2, "big_min": 96, "big_keep": 32}
+DEFAULTS = {"variant": 0, "grid_blocks": 1024, "chunk": 256, "refill_min": 16, "exit_max": 16, "xcd_affinity": 0, "wide": 2, "stack_lds": 0, "tri_min": 0, "fuse": 0, "exact_grids": 1, "steal": 8, "tail": 1, "big": 2, "big_min": 96, "big_keep": 32, "static_small": 8}
 
 
 def main():
