@@ -436,6 +436,15 @@ def main():
                     "peak_GBs": HBM_PEAK_GBS, "node_bytes": node_bytes,
                     "note": "alg = 80 B x node visits + 48 B x triangle tests + 44 B x walked rays; served mostly by L2 / Infinity "
                             "Cache on C2-C4 (so alg_GBs may exceed the HBM peak); hbm_frac = fabric-side counter bytes / time / peak"},
+            # the CU's vector-memory path: per-lane 16-B gathers (5 per node visit, 3 per triangle test) per microsecond per CU,
+            # beside what a loop that only gathers reaches on this chip (tools/gather_rate.hip, profiles/r2_gather_rate.txt:
+            # measured capacities, no datasheet figure; TUNING.md "What bounds bounces >= 1").  Averaged over all launches of the
+            # step, i.e. including bounce 0, whose 64 lanes share one line per instruction
+            "vmem": {"lane_loads_per_launch": int((5 * node_visits_sample + 3 * tri_tests_sample) * per_launch),
+                     "lane_loads_per_us_per_cu": round((5 * node_visits_sample + 3 * tri_tests_sample) * per_launch
+                                                       / (avg_ms * 1e3) / max(1, int(occ.compute_units)), 1),
+                     "gather_only_loop_per_us_per_cu": {"l1": 8900, "l2": 3700, "16MiB_table": 2600, "infinity_cache": 2400},
+                     "source": "profiles/r2_gather_rate.txt"},
             # static wavefront occupancy of that kernel against the gfx950 limit (32 waves per CU)
             "occupancy": {"waves_per_cu": int(occ.waves_per_cu), "max_waves_per_cu": int(occ.max_waves_per_cu),
                           "frac": round(occ.waves_per_cu / max(1, occ.max_waves_per_cu), 3), "vgprs": int(occ.vgprs),
