@@ -58,6 +58,9 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo_matches_one_rank(tmp_path):
         line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1]
         outs[n] = (json.loads(line), open(dump + ".pfm", "rb").read())
     assert outs[1][0]["ranks_seen"] == 1
+    roof = outs[1][0]["roofline"]  # the line carries the three sides of the dominant kernel
+    assert 0.0 < roof["frac"] <= 1.0 and roof["hbm"]["alg_bytes_per_launch"] > 0
+    assert roof["vmem"]["lane_loads_per_launch"] > 0 and roof["vmem"]["lane_loads_per_us_per_cu"] > 0
     a = np.frombuffer(outs[1][1][-1280 * 720 * 12:], "<f4")
     for n in (2, "self"):
         assert outs[n][0]["ranks_seen"] == 2 and outs[n][0]["n_gpus"] == 2, n
