@@ -443,7 +443,7 @@ def main():
             "vmem": {"lane_loads_per_launch": int((5 * node_visits_sample + 3 * tri_tests_sample) * per_launch),
                      "lane_loads_per_us_per_cu": round((5 * node_visits_sample + 3 * tri_tests_sample) * per_launch
                                                        / (avg_ms * 1e3) / max(1, int(occ.compute_units)), 1),
-                     "gather_only_loop_per_us_per_cu": {"l1": 8900, "l2": 3700, "16MiB_table": 2600, "infinity_cache": 2400},
+                     "gather_only_loop_per_us_per_cu": {"l1": 8900, "l2": 3700, "16MiB_table": 2600, "infinity_cache": 2400, "hbm_1GiB_table": 1540},
                      "source": "profiles/r2_gather_rate.txt"},
             # static wavefront occupancy of that kernel against the gfx950 limit (32 waves per CU)
             "occupancy": {"waves_per_cu": int(occ.waves_per_cu), "max_waves_per_cu": int(occ.max_waves_per_cu),
